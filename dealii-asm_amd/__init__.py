@@ -1,0 +1,361 @@
+"""ctypes binding of libdealii_asm_amd.so (the C ABI in include/dealii_asm_amd.h).
+
+Host-side mirror, for tests and bench.py, of the reference's operator surface:
+  LaplaceOperatorMatrixFree.vmult / compute_inverse_diagonal  (include/operator.h)
+  ASPoissonPreconditioner.vmult                               (include/matrix_free.h)
+  PreconditionChebyshev.vmult / step / estimate_eigenvalues   (deal.II, configured in
+                                                               include/precondition.templates.h:89-158)
+The product path has NO CPU fallback: importing works without a GPU (so that the
+exported symbols can be checked), creating a Context without one raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdealii_asm_amd.so")
+
+BC = {"periodic": 0, "dirichlet": 1, "neumann": 2}
+WEIGHTING = {"none": 0, "pre": 1, "post": 2, "ras": 3, "symm": 4}
+GEOMETRY = {"cartesian": 0, "kershaw": 1, "q2_points": 2}
+PRECOND = {"FDM": 0, "Diagonal": 1}
+EV = {"auto": 0, "lanczos": 1, "power iteration": 2}
+KERNEL = {"auto": 0, "generic": 1, "tiled": 2}
+
+
+class AsmParams(C.Structure):
+    _fields_ = [
+        ("degree", C.c_int32),
+        ("n_cells", C.c_int32 * 3),
+        ("boundary", (C.c_int32 * 2) * 3),
+        ("geometry", C.c_int32),
+        ("extent", C.c_double * 3),
+        ("kershaw_eps", C.c_double * 2),
+        ("q2_points", C.POINTER(C.c_double)),
+        ("precond_type", C.c_int32),
+        ("n_overlap", C.c_int32),
+        ("weighting_type", C.c_int32),
+        ("element_centric", C.c_int32),
+        ("cheb_degree", C.c_int32),
+        ("smoothing_range", C.c_double),
+        ("eig_n_iterations", C.c_int32),
+        ("ev_algorithm", C.c_int32),
+        ("kernel_variant", C.c_int32),
+        ("device", C.c_int32),
+        ("stream", C.c_void_p),
+        ("rank", C.c_int32),
+        ("world_size", C.c_int32),
+        ("proc_grid", C.c_int32 * 3),
+    ]
+
+
+class AsmLayout(C.Structure):
+    _fields_ = [
+        ("n_global_dofs", C.c_int64),
+        ("n_owned", C.c_int64),
+        ("n_ghost", C.c_int64),
+        ("n_alloc", C.c_int64),
+        ("owned_begin", C.c_int32 * 3),
+        ("owned_size", C.c_int32 * 3),
+        ("store_begin", C.c_int32 * 3),
+        ("store_size", C.c_int32 * 3),
+        ("stride", C.c_int64 * 3),
+        ("cell_begin", C.c_int32 * 3),
+        ("cell_size", C.c_int32 * 3),
+        ("proc_grid", C.c_int32 * 3),
+        ("proc_coord", C.c_int32 * 3),
+    ]
+
+
+# every symbol declared in include/dealii_asm_amd.h
+EXPORTED_SYMBOLS = [
+    "asm_params_default",
+    "asm_create",
+    "asm_destroy",
+    "asm_last_error",
+    "asm_describe_layout",
+    "asm_comm_unique_id",
+    "asm_comm_init",
+    "asm_vector_layout",
+    "asm_vector_alloc",
+    "asm_vector_free",
+    "asm_vector_import",
+    "asm_vector_export",
+    "asm_update_ghost_values",
+    "asm_compress_add",
+    "asm_op_vmult",
+    "asm_op_inverse_diagonal",
+    "asm_precond_vmult",
+    "asm_cheb_estimate_eigenvalues",
+    "asm_cheb_set_eigenvalue",
+    "asm_cheb_vmult",
+    "asm_cheb_step",
+    "asm_n_fdm_instances",
+    "asm_memory_consumption",
+    "asm_cheb_parameters",
+    "asm_kernel_variant_in_use",
+    "asm_synchronize",
+    "asm_time_calls",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C dealii-asm_amd` "
+            "(or __graft_entry__.build()); there is no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.asm_last_error.restype = C.c_char_p
+    lib.asm_last_error.argtypes = [C.c_void_p]
+    lib.asm_params_default.argtypes = [C.POINTER(AsmParams)]
+    lib.asm_params_default.restype = None
+    lib.asm_create.argtypes = [C.POINTER(AsmParams), C.POINTER(C.c_void_p)]
+    lib.asm_destroy.argtypes = [C.c_void_p]
+    lib.asm_destroy.restype = None
+    lib.asm_describe_layout.argtypes = [C.POINTER(AsmParams), C.POINTER(AsmLayout)]
+    lib.asm_vector_layout.argtypes = [C.c_void_p, C.POINTER(AsmLayout)]
+    lib.asm_vector_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.asm_vector_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.asm_vector_import.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.asm_vector_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    for name in ("asm_update_ghost_values", "asm_compress_add", "asm_op_inverse_diagonal"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
+    for name in ("asm_op_vmult", "asm_precond_vmult", "asm_cheb_vmult", "asm_cheb_step"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.asm_cheb_estimate_eigenvalues.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.asm_cheb_set_eigenvalue.argtypes = [C.c_void_p, C.c_double]
+    lib.asm_n_fdm_instances.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.asm_memory_consumption.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.asm_cheb_parameters.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.asm_kernel_variant_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.asm_synchronize.argtypes = [C.c_void_p]
+    lib.asm_time_calls.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.asm_comm_unique_id.argtypes = [C.c_char_p]
+    lib.asm_comm_init.argtypes = [C.c_void_p, C.c_char_p]
+    _lib = lib
+    return lib
+
+
+def make_params(
+    degree=4,
+    n_cells=(8, 8, 8),
+    boundary="dirichlet",
+    geometry="cartesian",
+    extent=(1.0, 1.0, 1.0),
+    kershaw_eps=(1.0, 1.0),
+    q2_points=None,
+    precond="FDM",
+    n_overlap=1,
+    weighting="post",
+    element_centric=True,
+    cheb_degree=3,
+    smoothing_range=20.0,
+    eig_n_iterations=40,
+    ev_algorithm="auto",
+    kernel="auto",
+    device=-1,
+    stream=None,
+    rank=0,
+    world_size=1,
+    proc_grid=(0, 0, 0),
+):
+    """Fill an asm_params with the reference's key names as keyword arguments
+    (include/precondition.templates.h:108-152, 195-211)."""
+    lib = load_library()
+    p = AsmParams()
+    lib.asm_params_default(C.byref(p))
+    p.degree = degree
+    if isinstance(boundary, str):
+        boundary = [(boundary, boundary)] * 3
+    for d in range(3):
+        p.n_cells[d] = int(n_cells[d])
+        b = boundary[d]
+        if isinstance(b, str):
+            b = (b, b)
+        p.boundary[d][0] = BC[b[0]]
+        p.boundary[d][1] = BC[b[1]]
+        p.extent[d] = float(extent[d])
+        p.proc_grid[d] = int(proc_grid[d])
+    p.geometry = GEOMETRY[geometry]
+    p.kershaw_eps[0], p.kershaw_eps[1] = float(kershaw_eps[0]), float(kershaw_eps[1])
+    keep = None
+    if q2_points is not None:
+        keep = np.ascontiguousarray(q2_points, dtype=np.float64)
+        p.q2_points = keep.ctypes.data_as(C.POINTER(C.c_double))
+    p.precond_type = PRECOND[precond]
+    p.n_overlap = n_overlap
+    p.weighting_type = WEIGHTING[weighting]
+    p.element_centric = 1 if element_centric else 0
+    p.cheb_degree = cheb_degree
+    p.smoothing_range = smoothing_range
+    p.eig_n_iterations = eig_n_iterations
+    p.ev_algorithm = EV[ev_algorithm]
+    p.kernel_variant = KERNEL[kernel]
+    p.device = device
+    p.stream = stream
+    p.rank = rank
+    p.world_size = world_size
+    p._keepalive = keep
+    return p
+
+
+def describe_layout(params: AsmParams) -> AsmLayout:
+    lib = load_library()
+    out = AsmLayout()
+    err = lib.asm_describe_layout(C.byref(params), C.byref(out))
+    if err:
+        raise ValueError(lib.asm_last_error(None).decode())
+    return out
+
+
+class DeviceVector:
+    """A device buffer in the library's box layout (initialize_dof_vector)."""
+
+    def __init__(self, ctx: "Context"):
+        self.ctx = ctx
+        ptr = C.c_void_p()
+        ctx._check(ctx.lib.asm_vector_alloc(ctx.handle, C.byref(ptr)))
+        self.ptr = ptr
+
+    def set(self, host_owned):
+        a = np.ascontiguousarray(host_owned, dtype=np.float64).reshape(-1)
+        assert a.size == self.ctx.layout.n_owned, (a.size, self.ctx.layout.n_owned)
+        self.ctx._check(self.ctx.lib.asm_vector_import(self.ctx.handle, self.ptr, a.ctypes.data_as(C.c_void_p)))
+        return self
+
+    def get(self):
+        out = np.empty(self.ctx.layout.n_owned, dtype=np.float64)
+        self.ctx._check(self.ctx.lib.asm_vector_export(self.ctx.handle, out.ctypes.data_as(C.c_void_p), self.ptr))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle is not None:
+            self.ctx.lib.asm_vector_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+
+class Context:
+    """Operator + preconditioner + Chebyshev smoother on one GPU."""
+
+    def __init__(self, params: AsmParams | None = None, **kw):
+        self.lib = load_library()
+        self.params = params if params is not None else make_params(**kw)
+        h = C.c_void_p()
+        err = self.lib.asm_create(C.byref(self.params), C.byref(h))
+        if err:
+            raise RuntimeError(f"asm_create failed ({err}): {self.lib.asm_last_error(None).decode()}")
+        self.handle = h
+        self.layout = AsmLayout()
+        self._check(self.lib.asm_vector_layout(self.handle, C.byref(self.layout)))
+
+    def _check(self, err):
+        if err:
+            raise RuntimeError(f"dealii_asm_amd error {err}: {self.lib.asm_last_error(self.handle).decode()}")
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.asm_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- vectors ------------------------------------------------------------
+    def vector(self, host_owned=None):
+        v = DeviceVector(self)
+        if host_owned is not None:
+            v.set(host_owned)
+        return v
+
+    @property
+    def n_owned(self):
+        return int(self.layout.n_owned)
+
+    @property
+    def n_dofs(self):
+        return int(self.layout.n_global_dofs)
+
+    # -- operators (names follow the reference) -------------------------------
+    def op_vmult(self, dst, src):
+        self._check(self.lib.asm_op_vmult(self.handle, dst.ptr, src.ptr))
+
+    def op_inverse_diagonal(self, out):
+        self._check(self.lib.asm_op_inverse_diagonal(self.handle, out.ptr))
+
+    def precond_vmult(self, dst, src):
+        self._check(self.lib.asm_precond_vmult(self.handle, dst.ptr, src.ptr))
+
+    def estimate_eigenvalues(self):
+        lam = C.c_double()
+        self._check(self.lib.asm_cheb_estimate_eigenvalues(self.handle, C.byref(lam)))
+        return lam.value
+
+    def set_eigenvalue(self, lam):
+        self._check(self.lib.asm_cheb_set_eigenvalue(self.handle, float(lam)))
+
+    def cheb_vmult(self, dst, src):
+        self._check(self.lib.asm_cheb_vmult(self.handle, dst.ptr, src.ptr))
+
+    def cheb_step(self, dst, src):
+        self._check(self.lib.asm_cheb_step(self.handle, dst.ptr, src.ptr))
+
+    def update_ghost_values(self, v):
+        self._check(self.lib.asm_update_ghost_values(self.handle, v.ptr))
+
+    def compress_add(self, v):
+        self._check(self.lib.asm_compress_add(self.handle, v.ptr))
+
+    def synchronize(self):
+        self._check(self.lib.asm_synchronize(self.handle))
+
+    def n_fdm_instances(self):
+        n = C.c_int64()
+        self._check(self.lib.asm_n_fdm_instances(self.handle, C.byref(n)))
+        return n.value
+
+    def memory_consumption(self):
+        n = C.c_int64()
+        self._check(self.lib.asm_memory_consumption(self.handle, C.byref(n)))
+        return n.value
+
+    def cheb_parameters(self):
+        out = (C.c_double * 3)()
+        self._check(self.lib.asm_cheb_parameters(self.handle, out))
+        return {"theta": out[0], "delta": out[1], "lambda_max": out[2]}
+
+    def kernel_variant(self):
+        v = C.c_int32()
+        self._check(self.lib.asm_kernel_variant_in_use(self.handle, C.byref(v)))
+        return {1: "generic", 2: "tiled"}.get(v.value, str(v.value))
+
+    def time_calls(self, what, reps, dst, src):
+        """HIP-event time (ms) of `reps` back-to-back calls; what in
+        op_vmult|precond_vmult|cheb_vmult|cheb_step."""
+        idx = {"op_vmult": 0, "precond_vmult": 1, "cheb_vmult": 2, "cheb_step": 3}[what]
+        ms = C.c_float()
+        self._check(self.lib.asm_time_calls(self.handle, idx, reps, dst.ptr, src.ptr, C.byref(ms)))
+        return ms.value
+
+    def comm_init(self, unique_id: bytes):
+        self._check(self.lib.asm_comm_init(self.handle, unique_id))
+
+
+def comm_unique_id() -> bytes:
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    if lib.asm_comm_unique_id(buf):
+        raise RuntimeError("ncclGetUniqueId failed")
+    return buf.raw

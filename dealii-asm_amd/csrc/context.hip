@@ -1,0 +1,919 @@
+// Context, C ABI, Chebyshev driver and ghost exchange.
+//
+// Host-side mirror of the reference's operator stack for the hot path:
+//   LaplaceOperatorMatrixFree         include/operator.h:266-1628
+//   ASPoissonPreconditioner           include/matrix_free.h:63-1568
+//   MFRunner / VectorDataExchange     include/matrix_free_internal.h:3-364
+//   PreconditionChebyshev (deal.II)   configured at include/precondition.templates.h:89-158
+#include "../../include/dealii_asm_amd.h"
+#include "kernels.h"
+#include "setup.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace asmamd;
+
+static thread_local std::string g_create_error;
+
+struct asm_ctx
+{
+  HostSetup                s;
+  std::unique_ptr<Basis1D> basis;
+  hipStream_t              stream = nullptr;
+  DevGrid                  g;
+  DevFdm                   f;
+  DevOp                    op;
+  std::vector<void *>      allocs;
+  long long                data_bytes = 0;
+  double *                 inv_diag   = nullptr;
+  double *                 R = nullptr, *T = nullptr, *S = nullptr; // scratch vectors
+  double *                 d_scalar = nullptr;
+  double *                 h_scalar = nullptr; // pinned
+  double                   lambda_max = 0., theta = 0., delta = 0.;
+  bool                     ev_set     = false;
+  ncclComm_t               comm       = nullptr;
+  double *                 hbuf[4]    = {nullptr, nullptr, nullptr, nullptr}; // send lo/hi, recv lo/hi
+  long long                hbuf_size  = 0;
+  std::string              error;
+};
+
+#define HIP_TRY(expr)                                                                              \
+  do                                                                                               \
+    {                                                                                              \
+      const hipError_t e_ = (expr);                                                                \
+      if (e_ != hipSuccess)                                                                        \
+        {                                                                                          \
+          ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+          return ASM_ERR_DEVICE;                                                                   \
+        }                                                                                          \
+    }                                                                                              \
+  while (0)
+
+#define NCCL_TRY(expr)                                                                             \
+  do                                                                                               \
+    {                                                                                              \
+      const ncclResult_t e_ = (expr);                                                              \
+      if (e_ != ncclSuccess)                                                                       \
+        {                                                                                          \
+          ctx->error = std::string(#expr) + ": " + ncclGetErrorString(e_);                         \
+          return ASM_ERR_DEVICE;                                                                   \
+        }                                                                                          \
+    }                                                                                              \
+  while (0)
+
+namespace
+{
+  template <typename T>
+  int
+  upload(asm_ctx *ctx, const std::vector<T> &h, const T **d)
+  {
+    *d = nullptr;
+    if (h.empty())
+      return ASM_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, h.size() * sizeof(T)));
+    ctx->allocs.push_back(p);
+    ctx->data_bytes += h.size() * sizeof(T);
+    HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = (const T *)p;
+    return ASM_OK;
+  }
+
+  int
+  alloc_vec(asm_ctx *ctx, double **v)
+  {
+    HIP_TRY(hipMalloc((void **)v, ctx->s.n_alloc * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(*v, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+    return ASM_OK;
+  }
+
+  bool
+  multi_rank(const asm_ctx *ctx)
+  {
+    return ctx->s.prm.world_size > 1;
+  }
+
+  // ---- ghost exchange ----------------------------------------------------
+  // dimension-by-dimension exchange of slabs (x, then y with the x ghosts, then z),
+  // the structured-block equivalent of Partitioner::export_to_ghosted_array
+  // (include/matrix_free_internal.h:13-47); add = true runs the reverse
+  // (import_from_ghosted_array with VectorOperation::add, :49-84) and zeroes
+  // the ghost planes afterwards (:86-103).
+  int
+  exchange(asm_ctx *ctx, double *v, const bool add)
+  {
+    if (!multi_rank(ctx))
+      return ASM_OK;
+    if (ctx->comm == nullptr)
+      {
+        ctx->error = "world_size > 1 but asm_comm_init() has not been called";
+        return ASM_ERR_INVALID_VALUE;
+      }
+    const DevGrid &g = ctx->g;
+    // ghost plane counts below plane 0 / from plane nc*p upwards; the same on every rank
+    const int n_lo = ctx->s.halo_lo, n_hi = ctx->s.halo_hi;
+    for (int step = 0; step < 3; ++step)
+      {
+        const int d  = add ? 2 - step : step;
+        const int np = g.nc[d] * g.p;
+        if (g.wrap[d])
+          continue;
+        const bool lo_if = ctx->s.face[d][0] == FACE_INTERFACE, hi_if = ctx->s.face[d][1] == FACE_INTERFACE;
+        // tangential extents: lower directions carry their ghost planes (update: they
+        // were filled before; add: they are forwarded afterwards), higher ones do not
+        int lo[3], size[3];
+        for (int e = 0; e < 3; ++e)
+          {
+            if (g.wrap[e])
+              {
+                lo[e]   = 0;
+                size[e] = g.nc[e] * g.p;
+              }
+            else if (e < d)
+              {
+                lo[e]   = g.ext_lo[e];
+                size[e] = g.ext_hi[e] - g.ext_lo[e] + 1;
+              }
+            else
+              {
+                lo[e]   = 0;
+                size[e] = g.own_hi[e] + 1;
+              }
+          }
+        const long long plane = (long long)(d == 0 ? 1 : size[0]) * (d == 1 ? 1 : size[1]) * (d == 2 ? 1 : size[2]);
+        // [0]: exchanged with the LOW neighbour, [1]: with the HIGH neighbour
+        // owned planes the neighbours ghost:   low neighbour: [0, n_hi)   high neighbour: [np - n_lo, np)
+        // my ghost planes:                     low: [-n_lo, 0)            high: [np, np + n_hi)
+        int own_lo[2] = {0, np - n_lo}, own_n[2] = {lo_if ? n_hi : 0, hi_if ? n_lo : 0};
+        int gh_lo[2] = {-n_lo, np}, gh_n[2] = {lo_if ? n_lo : 0, hi_if ? n_hi : 0};
+        int send_lo[2][3], send_size[2][3], recv_lo[2][3], recv_size[2][3];
+        long long cnt_send[2], cnt_recv[2];
+        for (int sd = 0; sd < 2; ++sd)
+          {
+            for (int e = 0; e < 3; ++e)
+              {
+                send_lo[sd][e] = recv_lo[sd][e] = lo[e];
+                send_size[sd][e] = recv_size[sd][e] = size[e];
+              }
+            send_lo[sd][d]   = add ? gh_lo[sd] : own_lo[sd];
+            send_size[sd][d] = add ? gh_n[sd] : own_n[sd];
+            recv_lo[sd][d]   = add ? own_lo[sd] : gh_lo[sd];
+            recv_size[sd][d] = add ? own_n[sd] : gh_n[sd];
+            cnt_send[sd]     = plane * send_size[sd][d];
+            cnt_recv[sd]     = plane * recv_size[sd][d];
+            if (cnt_send[sd] > ctx->hbuf_size || cnt_recv[sd] > ctx->hbuf_size)
+              {
+                ctx->error = "internal error: halo buffer too small";
+                return ASM_ERR_INVALID_VALUE;
+              }
+            if (cnt_send[sd] > 0)
+              vec_box(g, 0, v, ctx->hbuf[sd], send_lo[sd], send_size[sd], ctx->stream);
+          }
+        NCCL_TRY(ncclGroupStart());
+        // sends: low then high; receives: high then low, so that with two ranks in a
+        // periodic direction (both neighbours are the same peer) the k-th send of one
+        // side meets the k-th receive of the other
+        for (int sd = 0; sd < 2; ++sd)
+          if (cnt_send[sd] > 0)
+            NCCL_TRY(ncclSend(ctx->hbuf[sd], cnt_send[sd], ncclDouble, ctx->s.nbr[d][sd], ctx->comm, ctx->stream));
+        for (int sd = 1; sd >= 0; --sd)
+          if (cnt_recv[sd] > 0)
+            NCCL_TRY(ncclRecv(ctx->hbuf[2 + sd], cnt_recv[sd], ncclDouble, ctx->s.nbr[d][sd], ctx->comm, ctx->stream));
+        NCCL_TRY(ncclGroupEnd());
+        for (int sd = 0; sd < 2; ++sd)
+          if (cnt_recv[sd] > 0)
+            vec_box(g, add ? 2 : 1, v, ctx->hbuf[2 + sd], recv_lo[sd], recv_size[sd], ctx->stream);
+        if (add) // zero_out_ghost_values
+          for (int sd = 0; sd < 2; ++sd)
+            if (cnt_send[sd] > 0)
+              vec_box(g, 3, v, nullptr, send_lo[sd], send_size[sd], ctx->stream);
+      }
+    return ASM_OK;
+  }
+
+  // global sum of a device scalar -> host
+  int
+  reduce_scalar(asm_ctx *ctx, double *out)
+  {
+    if (multi_rank(ctx))
+      {
+        if (ctx->comm == nullptr)
+          {
+            ctx->error = "world_size > 1 but asm_comm_init() has not been called";
+            return ASM_ERR_INVALID_VALUE;
+          }
+        NCCL_TRY(ncclAllReduce(ctx->d_scalar, ctx->d_scalar, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+      }
+    HIP_TRY(hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = *ctx->h_scalar;
+    return ASM_OK;
+  }
+
+  int
+  dot(asm_ctx *ctx, const double *x, const double *y, double *out)
+  {
+    HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
+    vec_dot(ctx->g, x, y, ctx->d_scalar, ctx->stream);
+    return reduce_scalar(ctx, out);
+  }
+
+  // ---- sweeps --------------------------------------------------------------
+  // dst = A src (OP_PLAIN) or dst = b - A src with identity rows on constrained
+  // DoFs (OP_RESIDUAL); src's ghosts are updated here.
+  int
+  op_apply(asm_ctx *ctx, const int mode, double *dst, double *src, const double *b)
+  {
+    int err = exchange(ctx, src, false);
+    if (err)
+      return err;
+    if (ctx->s.kernel == ASM_KERNEL_TILED)
+      {
+        TiledArgs a{mode, src, dst, b, nullptr, nullptr, 0., 0.};
+        if (!laplace_tiled(ctx->g, ctx->op, a, ctx->stream))
+          {
+            ctx->error = "tiled Laplace kernel not available for this configuration";
+            return ASM_ERR_NOT_SUPPORTED;
+          }
+        return ASM_OK;
+      }
+    HIP_TRY(hipMemsetAsync(dst, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+    if (!laplace_generic(ctx->g, ctx->op, src, dst, false, ctx->stream))
+      {
+        ctx->error = "generic Laplace kernel not available for this degree";
+        return ASM_ERR_NOT_SUPPORTED;
+      }
+    err = exchange(ctx, dst, true);
+    if (err)
+      return err;
+    if (mode == OP_RESIDUAL)
+      {
+        vec_residual(dst, b, ctx->s.n_alloc, ctx->stream);
+        vec_constrained(ctx->g, 2, dst, src, b, ctx->stream); // r_c = b_c - x_c
+      }
+    return ASM_OK;
+  }
+
+  // dst = [f(x, x_old) +] f2 * P^-1 src, see TiledMode
+  int
+  pc_apply(asm_ctx *ctx, const int mode, double *dst, double *src, const double *x, const double *x_old, const double f1,
+           const double f2)
+  {
+    const long long n = ctx->s.n_alloc;
+    if (ctx->s.prm.precond_type == ASM_PRECOND_DIAGONAL)
+      {
+        // DiagonalMatrixPrePost::vmult, include/preconditioners.h:965-993
+        double *t = (mode == PC_PLAIN) ? dst : ctx->T;
+        vec_mul(t, src, ctx->inv_diag, n, ctx->stream);
+        if (mode == PC_FIRST)
+          vec_scale(dst, t, f2, n, ctx->stream);
+        else if (mode == PC_STEP1)
+          {
+            vec_scale(dst, x, f1, n, ctx->stream);
+            vec_axpby(dst, f2, t, 1., n, ctx->stream);
+          }
+        else if (mode == PC_UPDATE)
+          vec_cheb_update(dst, x, x_old, t, f1, f2, n, ctx->stream);
+        return ASM_OK;
+      }
+    int err = exchange(ctx, src, false);
+    if (err)
+      return err;
+    if (ctx->s.kernel == ASM_KERNEL_TILED)
+      {
+        TiledArgs a{mode, src, dst, nullptr, x, x_old, f1, f2};
+        if (!fdm_tiled(ctx->g, ctx->f, a, ctx->stream))
+          {
+            ctx->error = "tiled FDM kernel not available for this configuration";
+            return ASM_ERR_NOT_SUPPORTED;
+          }
+        return ASM_OK;
+      }
+    double *t = (mode == PC_PLAIN) ? dst : ctx->T;
+    HIP_TRY(hipMemsetAsync(t, 0, n * sizeof(double), ctx->stream));
+    if (!fdm_generic(ctx->g, ctx->f, src, t, ctx->stream))
+      {
+        ctx->error = "generic FDM kernel not available for this patch size";
+        return ASM_ERR_NOT_SUPPORTED;
+      }
+    // RAS could skip this exchange in the reference (needs_compression, matrix_free.h:654-668);
+    // here the patch owning a shared plane may sit on the lower rank, so it stays
+    err = exchange(ctx, t, true);
+    if (err)
+      return err;
+    if (mode != PC_PLAIN)
+      vec_constrained(ctx->g, 1, t, src, nullptr, ctx->stream); // unit rows on constrained DoFs
+    if (mode == PC_FIRST)
+      vec_scale(dst, t, f2, n, ctx->stream);
+    else if (mode == PC_STEP1) // dst = f1 * x + f2 * t   (f1 carries 1 + factor1)
+      {
+        vec_scale(dst, x, f1, n, ctx->stream);
+        vec_axpby(dst, f2, t, 1., n, ctx->stream);
+      }
+    else if (mode == PC_UPDATE)
+      vec_cheb_update(dst, x, x_old, t, f1, f2, n, ctx->stream);
+    return ASM_OK;
+  }
+
+  // PreconditionChebyshev::vmult / step [deal.II], first-kind polynomial:
+  //   x_1     = x_0 + 1/theta P^-1 (b - A x_0)
+  //   x_{j+1} = x_j + rho_j rho_{j-1} (x_j - x_{j-1}) + 2 rho_j/delta P^-1 (b - A x_j)
+  int
+  cheb_run(asm_ctx *ctx, double *dst, const double *b, const bool zero_start)
+  {
+    if (!ctx->ev_set)
+      {
+        ctx->error = "Chebyshev eigenvalues not set: call asm_cheb_estimate_eigenvalues or asm_cheb_set_eigenvalue";
+        return ASM_ERR_INVALID_VALUE;
+      }
+    const int    degree = ctx->s.prm.cheb_degree;
+    const double theta = ctx->theta, delta = ctx->delta;
+    const bool   iterate = degree >= 2 && std::fabs(delta) >= 1e-40;
+    const int    k_total = iterate ? degree : 1;
+    double *     A = dst, *S = ctx->S, *R = ctx->R;
+    double *     cur, *prev; // cur holds x_j, prev holds x_{j-1}
+    int          err;
+    if (zero_start)
+      {
+        // the final iterate lands in A if the first one goes to A for odd k, to S for even k
+        cur = (k_total % 2) ? A : S;
+        err = pc_apply(ctx, PC_FIRST, cur, const_cast<double *>(b), nullptr, nullptr, 0., 1. / theta);
+        if (err)
+          return err;
+        prev = nullptr;
+      }
+    else
+      {
+        err = op_apply(ctx, OP_RESIDUAL, R, A, b);
+        if (err)
+          return err;
+        if (k_total == 1)
+          return pc_apply(ctx, PC_STEP1, A, R, A, nullptr, 1., 1. / theta);
+        err = pc_apply(ctx, PC_STEP1, S, R, A, nullptr, 1., 1. / theta);
+        if (err)
+          return err;
+        cur  = S;
+        prev = A;
+      }
+    double rhok = delta / theta;
+    const double sigma = theta / delta;
+    for (int k = 1; k < k_total; ++k)
+      {
+        const double rhokp = 1. / (2. * sigma - rhok);
+        const double f1 = rhokp * rhok, f2 = 2. * rhokp / delta;
+        rhok = rhokp;
+        err  = op_apply(ctx, OP_RESIDUAL, R, cur, b);
+        if (err)
+          return err;
+        if (prev == nullptr)
+          {
+            // x_0 = 0: x_2 = (1 + f1) x_1 + f2 t
+            double *out = (cur == A) ? S : A;
+            err         = pc_apply(ctx, PC_STEP1, out, R, cur, nullptr, 1. + f1, f2);
+            prev        = cur;
+            cur         = out;
+          }
+        else
+          {
+            err = pc_apply(ctx, PC_UPDATE, prev, R, cur, prev, f1, f2);
+            std::swap(cur, prev);
+          }
+        if (err)
+          return err;
+      }
+    if (cur != A)
+      HIP_TRY(hipMemcpyAsync(A, cur, ctx->s.n_alloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ASM_OK;
+  }
+
+  // eigenvalues of a symmetric tridiagonal matrix through the dense Jacobi solver
+  double
+  tridiag_max_eigenvalue(const std::vector<double> &diag, const std::vector<double> &off)
+  {
+    const int           k = diag.size();
+    std::vector<double> M(k * k, 0.), K(k * k, 0.), lam, Q;
+    for (int i = 0; i < k; ++i)
+      {
+        M[i * k + i] = 1.;
+        K[i * k + i] = diag[i];
+        if (i + 1 < k)
+          K[i * k + i + 1] = K[(i + 1) * k + i] = off[i];
+      }
+    generalized_eigen(k, M, K, lam, Q);
+    return lam.back();
+  }
+} // namespace
+
+extern "C" {
+
+void
+asm_params_default(asm_params *p)
+{
+  std::memset(p, 0, sizeof(*p));
+  p->degree = 4;
+  for (int d = 0; d < 3; ++d)
+    {
+      p->n_cells[d]     = 8;
+      p->boundary[d][0] = p->boundary[d][1] = ASM_BC_DIRICHLET;
+      p->extent[d]                          = 1.0;
+    }
+  p->geometry         = ASM_GEOM_CARTESIAN;
+  p->kershaw_eps[0]   = p->kershaw_eps[1] = 1.0;
+  p->precond_type     = ASM_PRECOND_FDM;
+  p->n_overlap        = 1;
+  p->weighting_type   = ASM_W_POST; // ctor default, include/matrix_free.h:81-82
+  p->element_centric  = 1;
+  p->cheb_degree      = 3;
+  p->smoothing_range  = 20.;
+  p->eig_n_iterations = 40;
+  p->ev_algorithm     = ASM_EV_AUTO;
+  p->kernel_variant   = ASM_KERNEL_AUTO;
+  p->device           = -1;
+  p->stream           = nullptr;
+  p->rank             = 0;
+  p->world_size       = 1;
+}
+
+const char *
+asm_last_error(const asm_ctx *ctx)
+{
+  return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int
+asm_describe_layout(const asm_params *p, asm_layout *out)
+{
+  HostSetup s;
+  if (!setup_layout(*p, s))
+    {
+      g_create_error = s.error;
+      return ASM_ERR_INVALID_VALUE;
+    }
+  fill_layout(s, out);
+  return ASM_OK;
+}
+
+int
+asm_create(const asm_params *p, asm_ctx **out)
+{
+  *out = nullptr;
+  std::unique_ptr<asm_ctx> holder(new asm_ctx);
+  asm_ctx *                ctx = holder.get();
+  const auto               fail = [&](const int code) {
+    g_create_error = ctx->error;
+    for (void *q : ctx->allocs)
+      (void)hipFree(q);
+    return code;
+  };
+  if (!setup_layout(*p, ctx->s))
+    {
+      ctx->error = ctx->s.error;
+      return fail(ASM_ERR_INVALID_VALUE);
+    }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+    {
+      ctx->error = "no HIP device available (the MI355X path has no CPU fallback)";
+      return fail(ASM_ERR_NO_DEVICE);
+    }
+  if (p->device >= 0 && hipSetDevice(p->device) != hipSuccess)
+    {
+      ctx->error = "hipSetDevice failed";
+      return fail(ASM_ERR_DEVICE);
+    }
+  ctx->stream = (hipStream_t)p->stream;
+  try
+    {
+      ctx->basis.reset(new Basis1D(p->degree));
+      if (!setup_all(ctx->s, *ctx->basis))
+        {
+          ctx->error = ctx->s.error;
+          return fail(ASM_ERR_INVALID_VALUE);
+        }
+    }
+  catch (const std::exception &e)
+    {
+      ctx->error = e.what();
+      return fail(ASM_ERR_INVALID_VALUE);
+    }
+  HostSetup &s = ctx->s;
+  ctx->g       = s.g;
+  int err;
+#define UP(vec, ptr)                 \
+  err = upload(ctx, vec, ptr);       \
+  if (err)                           \
+    return fail(err);
+  // operator data
+  DevOp &op    = ctx->op;
+  op.cartesian = s.cartesian;
+  for (int d = 0; d < 3; ++d)
+    {
+      UP(s.h[d], &op.h[d]);
+    }
+  UP(s.coeff, &op.coeff);
+  UP(ctx->basis->N, &op.N);
+  UP(ctx->basis->Dc, &op.Dc);
+  UP(ctx->basis->xq, &op.xq);
+  UP(ctx->basis->wq, &op.wq);
+  // FDM data
+  DevFdm &f = ctx->f;
+  std::memset(&f, 0, sizeof(f));
+  f.m           = s.m;
+  const bool vx = s.prm.element_centric == 0;
+  f.origin_mul  = s.g.p;
+  f.origin_add  = vx ? 1 : -(s.prm.n_overlap - 1);
+  f.vertex      = vx;
+  f.tensor_inst = s.tensor_inst;
+  if (s.prm.precond_type == ASM_PRECOND_FDM)
+    {
+      for (int d = 0; d < 3; ++d)
+        {
+          UP(s.inst[d], &f.inst[d]);
+          UP(s.w_pre[d], &f.w_pre[d]);
+          UP(s.w_post[d], &f.w_post[d]);
+        }
+      UP(s.eig, &f.eig);
+    }
+#undef UP
+  if (alloc_vec(ctx, &ctx->R) || alloc_vec(ctx, &ctx->T) || alloc_vec(ctx, &ctx->S))
+    return fail(ASM_ERR_DEVICE);
+  ctx->allocs.push_back(ctx->R);
+  ctx->allocs.push_back(ctx->T);
+  ctx->allocs.push_back(ctx->S);
+  if (hipMalloc((void **)&ctx->d_scalar, 64) != hipSuccess || hipHostMalloc((void **)&ctx->h_scalar, 64) != hipSuccess)
+    {
+      ctx->error = "allocation of reduction scalars failed";
+      return fail(ASM_ERR_DEVICE);
+    }
+  ctx->allocs.push_back(ctx->d_scalar);
+  if (multi_rank(ctx))
+    {
+      // largest slab: widest halo times the largest stored face
+      const long long a = s.store_size[0], b = s.store_size[1], c = s.store_size[2];
+      const long long face = std::max(a * b, std::max(a * c, b * c));
+      ctx->hbuf_size       = face * (2 * s.g.p + 2);
+      for (int i = 0; i < 4; ++i)
+        {
+          if (hipMalloc((void **)&ctx->hbuf[i], ctx->hbuf_size * sizeof(double)) != hipSuccess)
+            {
+              ctx->error = "halo buffer allocation failed";
+              return fail(ASM_ERR_DEVICE);
+            }
+          ctx->allocs.push_back(ctx->hbuf[i]);
+        }
+    }
+  if (s.prm.precond_type == ASM_PRECOND_DIAGONAL)
+    {
+      if (alloc_vec(ctx, &ctx->inv_diag))
+        return fail(ASM_ERR_DEVICE);
+      ctx->allocs.push_back(ctx->inv_diag);
+      if (!multi_rank(ctx)) // with several ranks the diagonal needs the communicator: done in asm_comm_init
+        {
+          err = asm_op_inverse_diagonal(ctx, ctx->inv_diag);
+          if (err)
+            return fail(err);
+        }
+    }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    {
+      ctx->error = "device error during setup";
+      return fail(ASM_ERR_DEVICE);
+    }
+  *out = holder.release();
+  return ASM_OK;
+}
+
+void
+asm_destroy(asm_ctx *ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm)
+    ncclCommDestroy(ctx->comm);
+  for (void *q : ctx->allocs)
+    (void)hipFree(q);
+  if (ctx->h_scalar)
+    (void)hipHostFree(ctx->h_scalar);
+  delete ctx;
+}
+
+int
+asm_comm_unique_id(char id[128])
+{
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId uid;
+  if (ncclGetUniqueId(&uid) != ncclSuccess)
+    return ASM_ERR_DEVICE;
+  std::memcpy(id, &uid, 128);
+  return ASM_OK;
+}
+
+int
+asm_comm_init(asm_ctx *ctx, const char id[128])
+{
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, 128);
+  NCCL_TRY(ncclCommInitRank(&ctx->comm, ctx->s.prm.world_size, uid, ctx->s.prm.rank));
+  if (ctx->s.prm.precond_type == ASM_PRECOND_DIAGONAL)
+    return asm_op_inverse_diagonal(ctx, ctx->inv_diag);
+  return ASM_OK;
+}
+
+int
+asm_vector_layout(const asm_ctx *ctx, asm_layout *out)
+{
+  fill_layout(ctx->s, out);
+  return ASM_OK;
+}
+
+int
+asm_vector_alloc(asm_ctx *ctx, double **v)
+{
+  return alloc_vec(ctx, v);
+}
+
+int
+asm_vector_free(asm_ctx *ctx, double *v)
+{
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipFree(v));
+  return ASM_OK;
+}
+
+int
+asm_vector_import(asm_ctx *ctx, double *dev, const double *host_owned)
+{
+  const DevGrid &g = ctx->g;
+  const int      lo[3] = {0, 0, 0}, size[3] = {g.own_hi[0] + 1, g.own_hi[1] + 1, g.own_hi[2] + 1};
+  double *       buf   = nullptr;
+  HIP_TRY(hipMalloc((void **)&buf, ctx->s.n_owned * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(buf, host_owned, ctx->s.n_owned * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(dev, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+  vec_box(g, 1, dev, buf, lo, size, ctx->stream);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipFree(buf));
+  return ASM_OK;
+}
+
+int
+asm_vector_export(asm_ctx *ctx, double *host_owned, const double *dev)
+{
+  const DevGrid &g = ctx->g;
+  const int      lo[3] = {0, 0, 0}, size[3] = {g.own_hi[0] + 1, g.own_hi[1] + 1, g.own_hi[2] + 1};
+  double *       buf   = nullptr;
+  HIP_TRY(hipMalloc((void **)&buf, ctx->s.n_owned * sizeof(double)));
+  vec_box(g, 0, const_cast<double *>(dev), buf, lo, size, ctx->stream);
+  HIP_TRY(hipMemcpyAsync(host_owned, buf, ctx->s.n_owned * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipFree(buf));
+  return ASM_OK;
+}
+
+int
+asm_update_ghost_values(asm_ctx *ctx, double *v)
+{
+  return exchange(ctx, v, false);
+}
+
+int
+asm_compress_add(asm_ctx *ctx, double *v)
+{
+  return exchange(ctx, v, true);
+}
+
+int
+asm_op_vmult(asm_ctx *ctx, double *dst, const double *src)
+{
+  return op_apply(ctx, OP_PLAIN, dst, const_cast<double *>(src), nullptr);
+}
+
+int
+asm_op_inverse_diagonal(asm_ctx *ctx, double *out)
+{
+  HIP_TRY(hipMemsetAsync(out, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+  if (!laplace_generic(ctx->g, ctx->op, nullptr, out, true, ctx->stream))
+    {
+      ctx->error = "generic Laplace kernel not available for this degree";
+      return ASM_ERR_NOT_SUPPORTED;
+    }
+  const int err = exchange(ctx, out, true);
+  if (err)
+    return err;
+  vec_invert_diagonal(out, ctx->s.n_alloc, ctx->stream);
+  return ASM_OK;
+}
+
+int
+asm_precond_vmult(asm_ctx *ctx, double *dst, const double *src)
+{
+  return pc_apply(ctx, PC_PLAIN, dst, const_cast<double *>(src), nullptr, nullptr, 0., 1.);
+}
+
+int
+asm_cheb_set_eigenvalue(asm_ctx *ctx, double lambda_max)
+{
+  if (!(lambda_max > 0.))
+    {
+      ctx->error = "eigenvalue estimate must be positive";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  // deal.II: max_eigenvalue = 1.2 * estimate; min = max / smoothing_range
+  ctx->lambda_max     = lambda_max;
+  const double max_ev = 1.2 * lambda_max;
+  const double min_ev = max_ev / ctx->s.prm.smoothing_range;
+  ctx->theta          = 0.5 * (max_ev + min_ev);
+  ctx->delta          = 0.5 * (max_ev - min_ev);
+  ctx->ev_set         = true;
+  return ASM_OK;
+}
+
+int
+asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max)
+{
+  const asm_params &prm = ctx->s.prm;
+  const long long   n   = ctx->s.n_alloc;
+  int               alg = prm.ev_algorithm;
+  if (alg == ASM_EV_AUTO)
+    {
+      // SymmetryType, include/matrix_free.h:896-904 and precondition.templates.h:113-114
+      const bool symmetric = prm.precond_type == ASM_PRECOND_DIAGONAL || prm.weighting_type == ASM_W_NONE ||
+                             prm.weighting_type == ASM_W_SYMM;
+      alg = symmetric ? ASM_EV_LANCZOS : ASM_EV_POWER_ITERATION;
+    }
+  double *v = nullptr, *w = nullptr, *z = nullptr, *q = nullptr;
+  if (alloc_vec(ctx, &v) || alloc_vec(ctx, &w) || alloc_vec(ctx, &z) || alloc_vec(ctx, &q))
+    return ASM_ERR_DEVICE;
+  const auto cleanup = [&](const int code) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(v);
+    (void)hipFree(w);
+    (void)hipFree(z);
+    (void)hipFree(q);
+    return code;
+  };
+  // set_initial_guess [deal.II]: (global index % 11) - mean, constrained entries zeroed
+  long long gbegin[3], gsize[3];
+  for (int d = 0; d < 3; ++d)
+    {
+      gbegin[d] = (long long)ctx->s.cell_begin[d] * prm.degree;
+      gsize[d]  = (long long)ctx->s.ncg[d] * prm.degree + (prm.boundary[d][0] == ASM_BC_PERIODIC ? 0 : 1);
+    }
+  const long long ng  = ctx->s.n_global;
+  const long long sum = (ng / 11) * 55 + ((ng % 11) * ((ng % 11) - 1)) / 2;
+  vec_initial_guess(ctx->g, v, gbegin, gsize, ctx->stream);
+  vec_add_scalar_owned(ctx->g, v, -(double)sum / (double)ng, ctx->stream);
+  vec_constrained(ctx->g, 0, v, nullptr, nullptr, ctx->stream);
+  int    err;
+  double est = 0.;
+  if (alg == ASM_EV_POWER_ITERATION)
+    {
+      double nrm2;
+      if ((err = dot(ctx, v, v, &nrm2)))
+        return cleanup(err);
+      vec_scale(v, v, 1. / std::sqrt(nrm2), n, ctx->stream);
+      for (int it = 0; it < prm.eig_n_iterations; ++it)
+        {
+          if ((err = op_apply(ctx, OP_PLAIN, w, v, nullptr)))
+            return cleanup(err);
+          if ((err = pc_apply(ctx, PC_PLAIN, z, w, nullptr, nullptr, 0., 1.)))
+            return cleanup(err);
+          if ((err = dot(ctx, v, z, &est)))
+            return cleanup(err);
+          if ((err = dot(ctx, z, z, &nrm2)))
+            return cleanup(err);
+          vec_scale(v, z, 1. / std::sqrt(nrm2), n, ctx->stream);
+        }
+      est = std::fabs(est);
+    }
+  else
+    {
+      // preconditioned CG started from x = 0, rhs = v; Lanczos matrix from the
+      // CG coefficients (deal.II SolverCG eigenvalue slot)
+      std::vector<double> alphas, betas;
+      double *            r = v, *pv = q;
+      double              rz, r0, tmp;
+      if ((err = pc_apply(ctx, PC_PLAIN, z, r, nullptr, nullptr, 0., 1.)))
+        return cleanup(err);
+      HIP_TRY(hipMemcpyAsync(pv, z, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      if ((err = dot(ctx, r, z, &rz)) || (err = dot(ctx, r, r, &r0)))
+        return cleanup(err);
+      r0 = std::sqrt(r0);
+      for (int it = 0; it < prm.eig_n_iterations; ++it)
+        {
+          if ((err = op_apply(ctx, OP_PLAIN, w, pv, nullptr)))
+            return cleanup(err);
+          if ((err = dot(ctx, pv, w, &tmp)))
+            return cleanup(err);
+          const double alpha = rz / tmp;
+          alphas.push_back(alpha);
+          vec_axpby(r, -alpha, w, 1., n, ctx->stream);
+          if ((err = dot(ctx, r, r, &tmp)))
+            return cleanup(err);
+          if (std::sqrt(tmp) < 1e-7 * r0)
+            break;
+          if ((err = pc_apply(ctx, PC_PLAIN, z, r, nullptr, nullptr, 0., 1.)))
+            return cleanup(err);
+          double rz_new;
+          if ((err = dot(ctx, r, z, &rz_new)))
+            return cleanup(err);
+          const double beta = rz_new / rz;
+          betas.push_back(beta);
+          rz = rz_new;
+          vec_axpby(pv, 1., z, beta, n, ctx->stream);
+        }
+      const int           k = alphas.size();
+      std::vector<double> dg(k), off(k > 0 ? k - 1 : 0);
+      for (int i = 0; i < k; ++i)
+        {
+          dg[i] = 1. / alphas[i] + (i > 0 ? betas[i - 1] / alphas[i - 1] : 0.);
+          if (i + 1 < k)
+            off[i] = std::sqrt(betas[i]) / alphas[i];
+        }
+      est = k > 0 ? tridiag_max_eigenvalue(dg, off) : 1.;
+    }
+  *lambda_max = est;
+  return cleanup(asm_cheb_set_eigenvalue(ctx, est));
+}
+
+int
+asm_cheb_vmult(asm_ctx *ctx, double *dst, const double *src)
+{
+  return cheb_run(ctx, dst, src, true);
+}
+
+int
+asm_cheb_step(asm_ctx *ctx, double *dst, const double *src)
+{
+  return cheb_run(ctx, dst, src, false);
+}
+
+int
+asm_n_fdm_instances(const asm_ctx *ctx, int64_t *n)
+{
+  *n = ctx->s.n_inst;
+  return ASM_OK;
+}
+
+int
+asm_memory_consumption(const asm_ctx *ctx, int64_t *bytes)
+{
+  *bytes = ctx->data_bytes;
+  return ASM_OK;
+}
+
+int
+asm_cheb_parameters(const asm_ctx *ctx, double out[3])
+{
+  out[0] = ctx->theta;
+  out[1] = ctx->delta;
+  out[2] = ctx->lambda_max;
+  return ASM_OK;
+}
+
+int
+asm_kernel_variant_in_use(const asm_ctx *ctx, int32_t *variant)
+{
+  *variant = ctx->s.kernel;
+  return ASM_OK;
+}
+
+int
+asm_synchronize(asm_ctx *ctx)
+{
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ASM_OK;
+}
+
+int
+asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms)
+{
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, ctx->stream));
+  int err = ASM_OK;
+  for (int i = 0; i < reps && !err; ++i)
+    switch (what)
+      {
+        case 0: err = asm_op_vmult(ctx, dst, src); break;
+        case 1: err = asm_precond_vmult(ctx, dst, src); break;
+        case 2: err = asm_cheb_vmult(ctx, dst, src); break;
+        case 3: err = asm_cheb_step(ctx, dst, src); break;
+        default: ctx->error = "asm_time_calls: unknown entry point"; err = ASM_ERR_INVALID_VALUE;
+      }
+  HIP_TRY(hipEventRecord(e1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return err;
+}
+} // extern "C"

@@ -1,0 +1,96 @@
+// Structured block of the hex mesh owned by one GPU, and the lexicographic box
+// layout of its DoF vectors in HBM.
+//
+// This replaces deal.II's DoFHandler / Utilities::MPI::Partitioner as used by
+// the reference (include/matrix_free.h:154-213, include/operator.h:780-849) and
+// the 27-start-index compression of include/vector_access_reduced.h: on a
+// structured mesh every patch of the reference (cell, cell + overlap layers,
+// vertex star; include/dof_tools.h:10-137, 206-300) is a contiguous BOX of the
+// lexicographic DoF grid, so no index lists are stored at all.
+#pragma once
+
+#include <cstdint>
+
+#ifdef __HIPCC__
+#  define ASM_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#  define ASM_HD inline
+#endif
+
+namespace asmamd
+{
+  // POD, passed by value to kernels
+  struct DevGrid
+  {
+    int p;  // polynomial degree
+    int n1; // p + 1
+    int nc[3]; // local cells per direction
+    // local logical DoF coordinate I of direction d: cell c covers [p c, p c + p]
+    int wrap[3];     // 1: periodic with a single rank in this direction -> I mod (nc p)
+    int ext_lo[3];   // smallest / largest logical coordinate that is stored
+    int ext_hi[3];
+    int dir_lo[3];   // 1: plane 0 / plane nc*p is a homogeneous Dirichlet boundary
+    int dir_hi[3];
+    int own_hi[3];   // last owned plane (owned range is [0, own_hi])
+    long long stride[3]; // element strides of the stored box (x fastest)
+
+    ASM_HD int n_planes(const int d) const { return nc[d] * p; }
+
+    // storage index along direction d of logical coordinate I (must exist)
+    ASM_HD int store_index(const int d, int I) const
+    {
+      if (wrap[d])
+        {
+          const int n = nc[d] * p;
+          I           = I % n;
+          return I < 0 ? I + n : I;
+        }
+      return I - ext_lo[d];
+    }
+    ASM_HD bool exists(const int d, const int I) const
+    {
+      return wrap[d] || (I >= ext_lo[d] && I <= ext_hi[d]);
+    }
+    ASM_HD bool dirichlet(const int d, const int I) const
+    {
+      return (dir_lo[d] && I == 0) || (dir_hi[d] && I == nc[d] * p);
+    }
+    ASM_HD long long offset(const int I, const int J, const int K) const
+    {
+      return store_index(0, I) * stride[0] + store_index(1, J) * stride[1] +
+             store_index(2, K) * stride[2];
+    }
+  };
+
+  enum PatchKind
+  {
+    PATCH_CELL   = 0, // element-centred, m = p - 1 + 2 n_overlap (matrix_free.h:90)
+    PATCH_VERTEX = 1  // vertex-star, m = 2p - 1 (matrix_free.h:91)
+  };
+
+  // per-direction tables of the FDM preconditioner (device pointers)
+  struct DevFdm
+  {
+    int m;          // patch size per direction
+    int origin_mul; // patch origin = origin_mul * c + origin_add
+    int origin_add;
+    int vertex;     // PATCH_VERTEX: patch invalid unless cell c+1 exists in all directions
+    int tensor_inst;       // 1: instance id depends on (d, c_d) only
+    const int *inst[3];    // [nc[d]] (tensor) or [ncells] (per cell): instance id of direction d
+    const double *eig;     // [n_inst][m*m + m]: Q (row i, col a) then lambda
+    const double *w_pre[3];  // [nc[d]][m] 1-D factors of the pre weight, or nullptr
+    const double *w_post[3]; // [nc[d]][m] 1-D factors of the post weight, or nullptr
+  };
+
+  // geometry + basis of the Laplace operator (device pointers)
+  struct DevOp
+  {
+    int cartesian;        // 1: h[d][c_d] cell sizes; 0: 27 monomial coefficient vectors per cell
+    const double *h[3];   // [nc[d]]
+    const double *coeff;  // [ncells][27][3] (operator.h:625-661 layout: index 9k+3j+i, component)
+    const double *N;      // [q][i]
+    const double *Dc;     // [q][r]
+    const double *xq;     // [q]
+    const double *wq;     // [q]
+  };
+} // namespace asmamd

@@ -1,0 +1,61 @@
+// Launch interfaces of the HIP kernels (all asynchronous on the given stream).
+#pragma once
+
+#include "grid.h"
+
+#include <hip/hip_runtime.h>
+
+namespace asmamd
+{
+  // ---- generic sweeps (kernels_generic.hip): dst must be zeroed by the caller,
+  //      contributions are added with fp64 atomics
+  bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, hipStream_t st);
+  bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st);
+
+  // ---- tiled owner-computes sweeps (kernels_tiled.hip), degree 4, n_overlap 1
+  enum TiledMode
+  {
+    // Laplace operator
+    OP_PLAIN    = 0, // dst = A src                         (constrained rows: 0)
+    OP_RESIDUAL = 1, // dst = b - A src                     (constrained rows: identity)
+    // FDM preconditioner
+    PC_PLAIN  = 2, // dst = P^-1 src                        (constrained rows: 0)
+    PC_FIRST  = 3, // dst = f2 * P^-1 src                   (constrained rows: identity)
+    PC_STEP1  = 4, // dst = x + f2 * P^-1 src
+    PC_UPDATE = 5  // dst = x + f1 (x - x_old) + f2 * P^-1 src ; dst may alias x_old
+  };
+  struct TiledArgs
+  {
+    int           mode;
+    const double *src;
+    double *      dst;
+    const double *b;     // OP_RESIDUAL
+    const double *x;     // PC_STEP1 / PC_UPDATE
+    const double *x_old; // PC_UPDATE
+    double        f1, f2;
+  };
+  bool laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st);
+  bool fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st);
+
+  // ---- vector kernels (kernels_vector.hip)
+  // elementwise over the whole allocation
+  void vec_residual(double *r, const double *b, long long n, hipStream_t st);                // r = b - r
+  void vec_scale(double *y, const double *x, double a, long long n, hipStream_t st);         // y = a x
+  void vec_mul(double *y, const double *x, const double *d, long long n, hipStream_t st);    // y = x .* d
+  void vec_axpby(double *y, double a, const double *x, double b, long long n, hipStream_t st); // y = a x + b y
+  // y = x + f1 (x - xo) + f2 t ; y may alias xo
+  void vec_cheb_update(double *y, const double *x, const double *xo, const double *t, double f1, double f2, long long n,
+                       hipStream_t st);
+  void vec_invert_diagonal(double *d, long long n, hipStream_t st); // |d|>1e-10 ? 1/d : 1
+  // reductions over the owned box; result[0] (device) accumulated, must be zeroed before
+  void vec_dot(const DevGrid &g, const double *x, const double *y, double *result, hipStream_t st);
+  // deal.II set_initial_guess: v = (global lexicographic index % 11)
+  void vec_initial_guess(const DevGrid &g, double *v, const long long gbegin[3], const long long gsize[3], hipStream_t st);
+  // v(owned) += a
+  void vec_add_scalar_owned(const DevGrid &g, double *v, double a, hipStream_t st);
+  // Dirichlet planes: mode 0: dst = 0 ; 1: dst = src ; 2: dst = b - x
+  void vec_constrained(const DevGrid &g, int mode, double *dst, const double *src, const double *b, hipStream_t st);
+  // box copy between a packed buffer and a vector (halo exchange, import/export)
+  // mode 0: buf <- vec ; 1: vec <- buf ; 2: vec += buf ; 3: vec <- 0
+  void vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st);
+} // namespace asmamd

@@ -1,0 +1,617 @@
+// Generic (any degree / any patch box) HIP kernels for gfx950.
+//
+//   fdm_generic_kernel<M>      ASPoissonPreconditioner::vmult_internal cell operation
+//                              (include/matrix_free.h:1023-1162): gather patch box ->
+//                              pre weights -> 6 one-dimensional eigenvector sweeps +
+//                              diagonal scaling (TensorProductMatrixSymmetricSum::
+//                              apply_inverse, deal.II) -> post weights -> scatter-add
+//   laplace_generic_kernel<P>  LaplaceOperatorMatrixFree::do_cell_integral_global
+//                              (include/operator.h:1335-1351) with the Cartesian or the
+//                              "quadratic geometry" Jacobians (:1035-1159)
+//
+// One thread owns one line of the patch tile; the tile lives in LDS between the
+// sweeps; the line being transformed lives in registers.  Neighbouring patches
+// overlap, so the scatter uses hardware fp64 atomics (global_atomic_add_f64).
+// These kernels are the general path (every degree 1..7, n_overlap, vertex-star
+// patches); the tiled kernels in kernels_tiled.hip are the fast path for the
+// headline configuration.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace asmamd
+{
+  namespace
+  {
+    constexpr int BLOCK = 256;
+
+    template <int M>
+    struct FdmCfg
+    {
+      static constexpr int M2  = M * M;
+      static constexpr int M3  = M * M * M;
+      static constexpr int CPB = (BLOCK / M2) > 0 ? (BLOCK / M2) : 1; // cells per block
+      static constexpr int E   = M2 + M;                              // eigen data per direction
+    };
+
+    // out[a] = sum_i Q[i][a] in[i]   (forward, Q^T)
+    template <int M>
+    __device__ __forceinline__ void
+    sweep_fwd(const double *__restrict__ Q, double (&u)[M])
+    {
+      double t[M];
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+        t[a] = 0.;
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+          t[a] = fma(Q[i * M + a], u[i], t[a]);
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+        u[a] = t[a];
+    }
+
+    // out[i] = sum_a Q[i][a] in[a]   (backward, Q)
+    template <int M>
+    __device__ __forceinline__ void
+    sweep_bwd(const double *__restrict__ Q, double (&u)[M])
+    {
+      double t[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+        {
+          double s = 0.;
+#pragma unroll
+          for (int a = 0; a < M; ++a)
+            s = fma(Q[i * M + a], u[a], s);
+          t[i] = s;
+        }
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+        u[i] = t[i];
+    }
+
+    template <int M>
+    __global__ void __launch_bounds__(BLOCK)
+    fdm_generic_kernel(const DevGrid g, const DevFdm f, const double *__restrict__ src, double *__restrict__ dst)
+    {
+      using C = FdmCfg<M>;
+      __shared__ double T[C::CPB][C::M3];
+      __shared__ double Qs[C::CPB][3][C::E];
+
+      const int  tid    = threadIdx.x;
+      const int  lc     = tid / C::M2;
+      const int  lt     = tid % C::M2;
+      const int  ncells = g.nc[0] * g.nc[1] * g.nc[2];
+      const int  cell   = blockIdx.x * C::CPB + lc;
+      const bool active = (lc < C::CPB) && (cell < ncells);
+
+      int c3[3] = {0, 0, 0};
+      if (active)
+        {
+          c3[0] = cell % g.nc[0];
+          c3[1] = (cell / g.nc[0]) % g.nc[1];
+          c3[2] = cell / (g.nc[0] * g.nc[1]);
+          // eigen data of the three directions -> LDS
+          const int ce = (c3[0] + 1) + (g.nc[0] + 2) * ((c3[1] + 1) + (g.nc[1] + 2) * (c3[2] + 1));
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            {
+              const int     id = f.tensor_inst ? f.inst[d][c3[d] + 1] : f.inst[d][ce];
+              const double *e  = f.eig + (long long)id * C::E;
+              Qs[lc][d][lt]    = e[lt];
+              if (lt < M)
+                Qs[lc][d][C::M2 + lt] = e[C::M2 + lt];
+            }
+        }
+
+      // thread (b, a) <-> lt = b*M + a
+      const int a = lt % M, b = lt / M;
+      const int o0 = f.origin_mul * c3[0] + f.origin_add, o1 = f.origin_mul * c3[1] + f.origin_add,
+                o2 = f.origin_mul * c3[2] + f.origin_add;
+
+      double u[M];
+      // ---- gather: thread (j=b, i=a) reads the column along z --------------
+      if (active)
+        {
+          const int    I = o0 + a, J = o1 + b;
+          const bool   exy = g.exists(0, I) && g.exists(1, J);
+          const double wxy = f.w_pre[0][(c3[0] + 1) * M + a] * f.w_pre[1][(c3[1] + 1) * M + b];
+          const long long base = exy ? (g.store_index(0, I) * g.stride[0] + g.store_index(1, J) * g.stride[1]) : 0;
+#pragma unroll
+          for (int k = 0; k < M; ++k)
+            {
+              const int    K = o2 + k;
+              const double w = wxy * f.w_pre[2][(c3[2] + 1) * M + k];
+              double       v = 0.;
+              if (exy && g.exists(2, K) && w != 0.)
+                v = src[base + g.store_index(2, K) * g.stride[2]] * w;
+              u[k] = v;
+            }
+        }
+      __syncthreads(); // Qs visible
+      if (active)
+        {
+          sweep_fwd<M>(Qs[lc][2], u); // z forward
+#pragma unroll
+          for (int k = 0; k < M; ++k)
+            T[lc][k * C::M2 + b * M + a] = u[k];
+        }
+      __syncthreads();
+      if (active)
+        {
+          // thread (k=b, i=a): column along y
+#pragma unroll
+          for (int j = 0; j < M; ++j)
+            u[j] = T[lc][b * C::M2 + j * M + a];
+          sweep_fwd<M>(Qs[lc][1], u);
+#pragma unroll
+          for (int j = 0; j < M; ++j)
+            T[lc][b * C::M2 + j * M + a] = u[j];
+        }
+      __syncthreads();
+      if (active)
+        {
+          // thread (k=b, j=a): row along x; forward, scale, backward
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+            u[i] = T[lc][b * C::M2 + a * M + i];
+          sweep_fwd<M>(Qs[lc][0], u);
+          const double lyz = Qs[lc][1][C::M2 + a] + Qs[lc][2][C::M2 + b];
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+            u[i] = u[i] / (Qs[lc][0][C::M2 + i] + lyz);
+          sweep_bwd<M>(Qs[lc][0], u);
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+            T[lc][b * C::M2 + a * M + i] = u[i];
+        }
+      __syncthreads();
+      if (active)
+        {
+          // thread (k=b, i=a): column along y, backward
+#pragma unroll
+          for (int j = 0; j < M; ++j)
+            u[j] = T[lc][b * C::M2 + j * M + a];
+          sweep_bwd<M>(Qs[lc][1], u);
+#pragma unroll
+          for (int j = 0; j < M; ++j)
+            T[lc][b * C::M2 + j * M + a] = u[j];
+        }
+      __syncthreads();
+      if (active)
+        {
+          // thread (j=b, i=a): column along z, backward, weights, scatter-add
+#pragma unroll
+          for (int k = 0; k < M; ++k)
+            u[k] = T[lc][k * C::M2 + b * M + a];
+          sweep_bwd<M>(Qs[lc][2], u);
+          const int    I = o0 + a, J = o1 + b;
+          const bool   exy = g.exists(0, I) && g.exists(1, J);
+          const double wxy = f.w_post[0][(c3[0] + 1) * M + a] * f.w_post[1][(c3[1] + 1) * M + b];
+          if (exy && wxy != 0.)
+            {
+              const long long base = g.store_index(0, I) * g.stride[0] + g.store_index(1, J) * g.stride[1];
+#pragma unroll
+              for (int k = 0; k < M; ++k)
+                {
+                  const int    K = o2 + k;
+                  const double w = wxy * f.w_post[2][(c3[2] + 1) * M + k];
+                  if (g.exists(2, K) && w != 0.)
+                    unsafeAtomicAdd(&dst[base + g.store_index(2, K) * g.stride[2]], u[k] * w);
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------
+    // Laplace operator
+    // ---------------------------------------------------------------------
+    template <int P>
+    struct OpCfg
+    {
+      static constexpr int N1  = P + 1;
+      static constexpr int N2  = N1 * N1;
+      static constexpr int N3  = N1 * N1 * N1;
+      static constexpr int CPB = (BLOCK / N2) > 0 ? (BLOCK / N2) : 1;
+    };
+
+    // out[q] = sum_i A[q][i] in[i]
+    template <int N>
+    __device__ __forceinline__ void
+    apply_mat(const double *__restrict__ A, double (&u)[N])
+    {
+      double t[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+        {
+          double s = 0.;
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+            s = fma(A[q * N + i], u[i], s);
+          t[q] = s;
+        }
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+        u[q] = t[q];
+    }
+    // out[i] = sum_q A[q][i] in[q]
+    template <int N>
+    __device__ __forceinline__ void
+    apply_mat_t(const double *__restrict__ A, double (&u)[N])
+    {
+      double t[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        t[i] = 0.;
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          t[i] = fma(A[q * N + i], u[q], t[i]);
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        u[i] = t[i];
+    }
+
+    // do_invert for 3x3, include/operator.h:891-914: t <- t^-1, returns det
+    __device__ __forceinline__ double
+    invert3(double (&t)[3][3])
+    {
+      const double tr00 = t[1][1] * t[2][2] - t[1][2] * t[2][1];
+      const double tr10 = t[1][2] * t[2][0] - t[1][0] * t[2][2];
+      const double tr20 = t[1][0] * t[2][1] - t[1][1] * t[2][0];
+      const double det  = t[0][0] * tr00 + t[0][1] * tr10 + t[0][2] * tr20;
+      const double inv  = 1.0 / det;
+      const double tr01 = t[0][2] * t[2][1] - t[0][1] * t[2][2];
+      const double tr02 = t[0][1] * t[1][2] - t[0][2] * t[1][1];
+      const double tr11 = t[0][0] * t[2][2] - t[0][2] * t[2][0];
+      const double tr12 = t[0][2] * t[1][0] - t[0][0] * t[1][2];
+      const double t21  = inv * (t[0][1] * t[2][0] - t[0][0] * t[2][1]);
+      const double t22  = inv * (t[0][0] * t[1][1] - t[0][1] * t[1][0]);
+      t[0][0]           = inv * tr00;
+      t[0][1]           = inv * tr01;
+      t[0][2]           = inv * tr02;
+      t[1][0]           = inv * tr10;
+      t[1][1]           = inv * tr11;
+      t[1][2]           = inv * tr12;
+      t[2][0]           = inv * tr20;
+      t[2][1]           = t21;
+      t[2][2]           = t22;
+      return det;
+    }
+
+    // Jacobian rows jac[d][e] = dX_e/dxi_d of the tri-quadratic map given by its 27
+    // monomial coefficient vectors v[9k+3j+i][e] (include/operator.h:1101-1128)
+    __device__ __forceinline__ void
+    q2_jacobian(const double *__restrict__ v, const double x, const double y, const double z, double (&jac)[3][3])
+    {
+      const double px[3] = {1., x, x * x}, py[3] = {1., y, y * y}, pz[3] = {1., z, z * z};
+      const double dx[3] = {0., 1., 2. * x}, dy[3] = {0., 1., 2. * y}, dz[3] = {0., 1., 2. * z};
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        jac[0][e] = jac[1][e] = jac[2][e] = 0.;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            {
+              const double w0 = dx[i] * py[j] * pz[k], w1 = px[i] * dy[j] * pz[k], w2 = px[i] * py[j] * dz[k];
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                {
+                  const double c = v[(9 * k + 3 * j + i) * 3 + e];
+                  jac[0][e]      = fma(w0, c, jac[0][e]);
+                  jac[1][e]      = fma(w1, c, jac[1][e]);
+                  jac[2][e]      = fma(w2, c, jac[2][e]);
+                }
+            }
+    }
+
+    // DIAG = false: dst += A src (scatter-add);  DIAG = true: dst += diag(A)
+    template <int P, bool DIAG>
+    __global__ void __launch_bounds__(BLOCK)
+    laplace_generic_kernel(const DevGrid g, const DevOp op, const double *__restrict__ src, double *__restrict__ dst)
+    {
+      using C           = OpCfg<P>;
+      constexpr int N1 = C::N1, N2 = C::N2, N3 = C::N3;
+      __shared__ double T0[C::CPB][N3], T1[C::CPB][N3], T2[C::CPB][N3];
+      __shared__ double Gs[C::CPB][81];
+      __shared__ double Ns[N2], Ds[N2], xqs[N1], wqs[N1];
+
+      const int  tid    = threadIdx.x;
+      const int  lc     = tid / N2;
+      const int  lt     = tid % N2;
+      const int  ncells = g.nc[0] * g.nc[1] * g.nc[2];
+      const int  cell   = blockIdx.x * C::CPB + lc;
+      const bool active = (lc < C::CPB) && (cell < ncells);
+      if (tid < N2)
+        {
+          Ns[tid] = op.N[tid];
+          Ds[tid] = op.Dc[tid];
+        }
+      if (tid < N1)
+        {
+          xqs[tid] = op.xq[tid];
+          wqs[tid] = op.wq[tid];
+        }
+      int c3[3] = {0, 0, 0};
+      if (active)
+        {
+          c3[0] = cell % g.nc[0];
+          c3[1] = (cell / g.nc[0]) % g.nc[1];
+          c3[2] = cell / (g.nc[0] * g.nc[1]);
+          if (!op.cartesian)
+            {
+              const long long ce = (c3[0] + 1) + (g.nc[0] + 2) * ((c3[1] + 1) + (long long)(g.nc[1] + 2) * (c3[2] + 1));
+              for (int e = lt; e < 81; e += N2)
+                Gs[lc][e] = op.coeff[ce * 81 + e];
+            }
+        }
+      const int a = lt % N1, b = lt / N1;
+
+      double    u[N1], uin[N1];
+      bool      valid[N1];
+      long long off[N1];
+      double    diag_acc[N1];
+      // ---- gather: thread (j=b, i=a) holds the column along z --------------
+      {
+        const int  I = P * c3[0] + a, J = P * c3[1] + b;
+        const bool vxy = active && g.exists(0, I) && g.exists(1, J) && !g.dirichlet(0, I) && !g.dirichlet(1, J);
+        const long long base = vxy ? (g.store_index(0, I) * g.stride[0] + g.store_index(1, J) * g.stride[1]) : 0;
+#pragma unroll
+        for (int k = 0; k < N1; ++k)
+          {
+            const int K = P * c3[2] + k;
+            valid[k]    = vxy && g.exists(2, K) && !g.dirichlet(2, K);
+            off[k]      = valid[k] ? base + g.store_index(2, K) * g.stride[2] : 0;
+            uin[k]      = (!DIAG && valid[k]) ? src[off[k]] : 0.;
+            diag_acc[k] = 0.;
+          }
+      }
+      __syncthreads();
+
+      for (int col = 0; col < (DIAG ? N3 : 1); ++col)
+        {
+          if (DIAG)
+            {
+#pragma unroll
+              for (int k = 0; k < N1; ++k)
+                uin[k] = (k * N2 + lt == col) ? 1. : 0.;
+            }
+#pragma unroll
+          for (int k = 0; k < N1; ++k)
+            u[k] = uin[k];
+          // interpolate to quadrature points: z (registers), y, x
+          if (active)
+            {
+              apply_mat<N1>(Ns, u);
+#pragma unroll
+              for (int k = 0; k < N1; ++k)
+                T0[lc][k * N2 + b * N1 + a] = u[k];
+            }
+          __syncthreads();
+          if (active)
+            {
+#pragma unroll
+              for (int j = 0; j < N1; ++j)
+                u[j] = T0[lc][b * N2 + j * N1 + a];
+              apply_mat<N1>(Ns, u);
+#pragma unroll
+              for (int j = 0; j < N1; ++j)
+                T0[lc][b * N2 + j * N1 + a] = u[j];
+            }
+          __syncthreads();
+          if (active)
+            {
+#pragma unroll
+              for (int i = 0; i < N1; ++i)
+                u[i] = T0[lc][b * N2 + a * N1 + i];
+              apply_mat<N1>(Ns, u);
+#pragma unroll
+              for (int i = 0; i < N1; ++i)
+                T0[lc][b * N2 + a * N1 + i] = u[i];
+            }
+          __syncthreads();
+          // gradients + geometry at the quadrature points: thread (qy=b, qx=a), loop qz
+          double hz[N1];
+          if (active)
+            {
+              double vz[N1];
+#pragma unroll
+              for (int q = 0; q < N1; ++q)
+                vz[q] = T0[lc][q * N2 + b * N1 + a];
+              double hxc = 1., hyc = 1., hzc = 1.;
+              if (op.cartesian)
+                {
+                  hxc = op.h[0][c3[0] + 1];
+                  hyc = op.h[1][c3[1] + 1];
+                  hzc = op.h[2][c3[2] + 1];
+                }
+#pragma unroll
+              for (int qz = 0; qz < N1; ++qz)
+                {
+                  double gx = 0., gy = 0., gz = 0.;
+#pragma unroll
+                  for (int r = 0; r < N1; ++r)
+                    {
+                      gx = fma(Ds[a * N1 + r], T0[lc][qz * N2 + b * N1 + r], gx);
+                      gy = fma(Ds[b * N1 + r], T0[lc][qz * N2 + r * N1 + a], gy);
+                      gz = fma(Ds[qz * N1 + r], vz[r], gz);
+                    }
+                  const double w = wqs[a] * wqs[b] * wqs[qz];
+                  double       ox, oy, oz;
+                  if (op.cartesian)
+                    {
+                      const double det = hxc * hyc * hzc * w;
+                      ox               = gx * det / (hxc * hxc);
+                      oy               = gy * det / (hyc * hyc);
+                      oz               = gz * det / (hzc * hzc);
+                    }
+                  else
+                    {
+                      double jac[3][3];
+                      q2_jacobian(Gs[lc], xqs[a], xqs[b], xqs[qz], jac);
+                      const double det = invert3(jac) * w;
+                      // tmp = G grad * det ; out = G^T tmp   (operator.h:1132-1152)
+                      const double t0 = (jac[0][0] * gx + jac[0][1] * gy + jac[0][2] * gz) * det;
+                      const double t1 = (jac[1][0] * gx + jac[1][1] * gy + jac[1][2] * gz) * det;
+                      const double t2 = (jac[2][0] * gx + jac[2][1] * gy + jac[2][2] * gz) * det;
+                      ox              = jac[0][0] * t0 + jac[1][0] * t1 + jac[2][0] * t2;
+                      oy              = jac[0][1] * t0 + jac[1][1] * t1 + jac[2][1] * t2;
+                      oz              = jac[0][2] * t0 + jac[1][2] * t1 + jac[2][2] * t2;
+                    }
+                  T1[lc][qz * N2 + b * N1 + a] = ox;
+                  T2[lc][qz * N2 + b * N1 + a] = oy;
+                  hz[qz]                        = oz;
+                }
+            }
+          __syncthreads();
+          if (active)
+            {
+              // integrate: collocation-derivative transposed
+#pragma unroll
+              for (int qz = 0; qz < N1; ++qz)
+                {
+                  double s = 0.;
+#pragma unroll
+                  for (int r = 0; r < N1; ++r)
+                    {
+                      s = fma(Ds[r * N1 + a], T1[lc][qz * N2 + b * N1 + r], s);
+                      s = fma(Ds[r * N1 + b], T2[lc][qz * N2 + r * N1 + a], s);
+                      s = fma(Ds[r * N1 + qz], hz[r], s);
+                    }
+                  u[qz] = s;
+                }
+              apply_mat_t<N1>(Ns, u); // z
+            }
+          __syncthreads(); // all reads of T0 (vz, rows) are done
+          if (active)
+            {
+#pragma unroll
+              for (int k = 0; k < N1; ++k)
+                T0[lc][k * N2 + b * N1 + a] = u[k];
+            }
+          __syncthreads();
+          if (active)
+            {
+#pragma unroll
+              for (int j = 0; j < N1; ++j)
+                u[j] = T0[lc][b * N2 + j * N1 + a];
+              apply_mat_t<N1>(Ns, u);
+#pragma unroll
+              for (int j = 0; j < N1; ++j)
+                T0[lc][b * N2 + j * N1 + a] = u[j];
+            }
+          __syncthreads();
+          if (active)
+            {
+#pragma unroll
+              for (int i = 0; i < N1; ++i)
+                u[i] = T0[lc][b * N2 + a * N1 + i];
+              apply_mat_t<N1>(Ns, u);
+#pragma unroll
+              for (int i = 0; i < N1; ++i)
+                T0[lc][b * N2 + a * N1 + i] = u[i];
+            }
+          __syncthreads();
+          if (active)
+            {
+              // thread (j=b, i=a): column along z
+#pragma unroll
+              for (int k = 0; k < N1; ++k)
+                {
+                  const double v = T0[lc][k * N2 + b * N1 + a];
+                  if (DIAG)
+                    {
+                      if (k * N2 + lt == col)
+                        diag_acc[k] = v;
+                    }
+                  else if (valid[k])
+                    unsafeAtomicAdd(&dst[off[k]], v);
+                }
+            }
+          __syncthreads();
+        }
+      if (DIAG && active)
+        {
+#pragma unroll
+          for (int k = 0; k < N1; ++k)
+            if (valid[k])
+              unsafeAtomicAdd(&dst[off[k]], diag_acc[k]);
+        }
+    }
+  } // namespace
+
+  // -----------------------------------------------------------------------
+  // launchers
+  // -----------------------------------------------------------------------
+  template <int M>
+  static void
+  launch_fdm(const DevGrid &g, const DevFdm &f, const double *src, double *dst, hipStream_t st)
+  {
+    const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
+    const int blocks = (ncells + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
+    hipLaunchKernelGGL(fdm_generic_kernel<M>, dim3(blocks), dim3(BLOCK), 0, st, g, f, src, dst);
+  }
+
+  bool
+  fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, hipStream_t st)
+  {
+    switch (f.m)
+      {
+        case 2: launch_fdm<2>(g, f, src, dst, st); break;
+        case 3: launch_fdm<3>(g, f, src, dst, st); break;
+        case 4: launch_fdm<4>(g, f, src, dst, st); break;
+        case 5: launch_fdm<5>(g, f, src, dst, st); break;
+        case 6: launch_fdm<6>(g, f, src, dst, st); break;
+        case 7: launch_fdm<7>(g, f, src, dst, st); break;
+        case 8: launch_fdm<8>(g, f, src, dst, st); break;
+        case 9: launch_fdm<9>(g, f, src, dst, st); break;
+        case 10: launch_fdm<10>(g, f, src, dst, st); break;
+        case 11: launch_fdm<11>(g, f, src, dst, st); break;
+        case 12: launch_fdm<12>(g, f, src, dst, st); break;
+        case 13: launch_fdm<13>(g, f, src, dst, st); break;
+        default: return false;
+      }
+    return true;
+  }
+
+  template <int P, bool DIAG>
+  static void
+  launch_op(const DevGrid &g, const DevOp &op, const double *src, double *dst, hipStream_t st)
+  {
+    const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
+    const int blocks = (ncells + OpCfg<P>::CPB - 1) / OpCfg<P>::CPB;
+    hipLaunchKernelGGL((laplace_generic_kernel<P, DIAG>), dim3(blocks), dim3(BLOCK), 0, st, g, op, src, dst);
+  }
+
+  bool
+  laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st)
+  {
+#define ASM_CASE(P)                              \
+  case P:                                        \
+    if (diag)                                    \
+      launch_op<P, true>(g, op, src, dst, st);   \
+    else                                         \
+      launch_op<P, false>(g, op, src, dst, st);  \
+    break;
+    switch (g.p)
+      {
+        ASM_CASE(1)
+        ASM_CASE(2)
+        ASM_CASE(3)
+        ASM_CASE(4)
+        ASM_CASE(5)
+        ASM_CASE(6)
+        ASM_CASE(7)
+        default: return false;
+      }
+#undef ASM_CASE
+    return true;
+  }
+} // namespace asmamd

@@ -1,0 +1,297 @@
+// Streaming vector kernels: Chebyshev updates (the "pre/post operations" of
+// PreconditionChebyshev that the reference passes as lambdas into
+// vmult(dst, src, pre, post), include/matrix_free.h:960-986), reductions for the
+// eigenvalue estimate, constrained-DoF handling
+// (MFWorker::apply_operation_to_constrained_dofs, include/matrix_free_internal.h:247-255)
+// and box pack/unpack for ghost exchange (VectorDataExchange, :3-109).
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace asmamd
+{
+  namespace
+  {
+    constexpr int VB = 256;
+
+    inline int
+    grid_for(const long long n, const int per_thread)
+    {
+      const long long blocks = (n + (long long)VB * per_thread - 1) / ((long long)VB * per_thread);
+      return (int)std::min<long long>(std::max<long long>(blocks, 1), 256 * 16);
+    }
+
+    template <typename F>
+    __global__ void __launch_bounds__(VB) elementwise2_kernel(const long long n2, F f)
+    {
+      // two doubles per lane and iteration (16-byte accesses)
+      for (long long i = blockIdx.x * (long long)VB + threadIdx.x; i < n2; i += (long long)gridDim.x * VB)
+        f(i);
+    }
+
+    struct ResidualOp
+    {
+      double2 *      r;
+      const double2 *b;
+      __device__ void operator()(const long long i) const
+      {
+        const double2 bv = b[i];
+        double2       rv = r[i];
+        rv.x             = bv.x - rv.x;
+        rv.y             = bv.y - rv.y;
+        r[i]             = rv;
+      }
+    };
+    struct ScaleOp
+    {
+      double2 *      y;
+      const double2 *x;
+      double         a;
+      __device__ void operator()(const long long i) const
+      {
+        double2 v = x[i];
+        v.x *= a;
+        v.y *= a;
+        y[i] = v;
+      }
+    };
+    struct MulOp
+    {
+      double2 *      y;
+      const double2 *x, *d;
+      __device__ void operator()(const long long i) const
+      {
+        double2       v = x[i];
+        const double2 w = d[i];
+        v.x *= w.x;
+        v.y *= w.y;
+        y[i] = v;
+      }
+    };
+    struct AxpbyOp
+    {
+      double2 *      y;
+      const double2 *x;
+      double         a, b;
+      __device__ void operator()(const long long i) const
+      {
+        const double2 xv = x[i];
+        double2       yv = y[i];
+        yv.x             = a * xv.x + b * yv.x;
+        yv.y             = a * xv.y + b * yv.y;
+        y[i]             = yv;
+      }
+    };
+    struct ChebOp
+    {
+      double2 *      y;
+      const double2 *x, *xo, *t;
+      double         f1, f2;
+      __device__ void operator()(const long long i) const
+      {
+        const double2 xv = x[i], ov = xo[i], tv = t[i];
+        double2       r;
+        r.x  = xv.x + f1 * (xv.x - ov.x) + f2 * tv.x;
+        r.y  = xv.y + f1 * (xv.y - ov.y) + f2 * tv.y;
+        y[i] = r;
+      }
+    };
+    struct InvDiagOp
+    {
+      double2 *d;
+      __device__ void operator()(const long long i) const
+      {
+        double2 v = d[i];
+        v.x       = fabs(v.x) > 1.0e-10 ? 1.0 / v.x : 1.0; // operator.h:1522-1523
+        v.y       = fabs(v.y) > 1.0e-10 ? 1.0 / v.y : 1.0;
+        d[i]      = v;
+      }
+    };
+
+    template <typename F>
+    void
+    launch2(const long long n, F f, hipStream_t st)
+    {
+      // allocations are multiples of 8 doubles (setup_layout pads the row pitch)
+      const long long n2 = n / 2;
+      hipLaunchKernelGGL(elementwise2_kernel<F>, dim3(grid_for(n2, 4)), dim3(VB), 0, st, n2, f);
+    }
+
+    __device__ __forceinline__ long long
+    owned_offset(const DevGrid &g, const long long e, int &I, int &J, int &K)
+    {
+      const int nx = g.own_hi[0] + 1, ny = g.own_hi[1] + 1;
+      I            = (int)(e % nx);
+      J            = (int)((e / nx) % ny);
+      K            = (int)(e / ((long long)nx * ny));
+      return g.offset(I, J, K);
+    }
+
+    __global__ void __launch_bounds__(VB)
+    dot_kernel(const DevGrid g, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ result)
+    {
+      const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+      double          s = 0.;
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          int             I, J, K;
+          const long long o = owned_offset(g, e, I, J, K);
+          s                 = fma(x[o], y[o], s);
+        }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+      __shared__ double part[VB / 64];
+      if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          double t = 0.;
+          for (int w = 0; w < VB / 64; ++w)
+            t += part[w];
+          unsafeAtomicAdd(result, t);
+        }
+    }
+
+    __global__ void __launch_bounds__(VB)
+    initial_guess_kernel(const DevGrid g, double *__restrict__ v, const long long gb0, const long long gb1, const long long gb2,
+                         const long long gs0, const long long gs1)
+    {
+      const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          int             I, J, K;
+          const long long o   = owned_offset(g, e, I, J, K);
+          const long long gid = (gb0 + I) + gs0 * ((gb1 + J) + gs1 * (gb2 + K));
+          v[o]                = (double)(gid % 11);
+        }
+    }
+
+    __global__ void __launch_bounds__(VB) add_scalar_owned_kernel(const DevGrid g, double *__restrict__ v, const double a)
+    {
+      const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          int             I, J, K;
+          const long long o = owned_offset(g, e, I, J, K);
+          v[o] += a;
+        }
+    }
+
+    // one launch over the (up to) six Dirichlet planes of the block
+    __global__ void __launch_bounds__(VB)
+    constrained_kernel(const DevGrid g, const int mode, double *__restrict__ dst, const double *__restrict__ src,
+                       const double *__restrict__ b)
+    {
+      const int face = blockIdx.y; // 2*d + side
+      const int d = face / 2, side = face % 2;
+      if (!(side ? g.dir_hi[d] : g.dir_lo[d]))
+        return;
+      const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+      // all stored planes of the two tangential directions
+      const int lo1 = g.wrap[d1] ? 0 : g.ext_lo[d1], n1 = (g.wrap[d1] ? g.nc[d1] * g.p - 1 : g.ext_hi[d1]) - lo1 + 1;
+      const int lo2 = g.wrap[d2] ? 0 : g.ext_lo[d2], n2 = (g.wrap[d2] ? g.nc[d2] * g.p - 1 : g.ext_hi[d2]) - lo2 + 1;
+      const long long n = (long long)n1 * n2;
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          int c[3];
+          c[d]  = side ? g.nc[d] * g.p : 0;
+          c[d1] = lo1 + (int)(e % n1);
+          c[d2] = lo2 + (int)(e / n1);
+          const long long o = g.offset(c[0], c[1], c[2]);
+          dst[o]            = mode == 0 ? 0. : (mode == 1 ? src[o] : b[o] - src[o]);
+        }
+    }
+
+    __global__ void __launch_bounds__(VB)
+    box_kernel(const DevGrid g, const int mode, double *__restrict__ vec, double *__restrict__ buf, const int l0, const int l1,
+               const int l2, const int s0, const int s1, const int s2)
+    {
+      const long long n = (long long)s0 * s1 * s2;
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          const int       i = (int)(e % s0), j = (int)((e / s0) % s1), k = (int)(e / ((long long)s0 * s1));
+          const long long o = g.offset(l0 + i, l1 + j, l2 + k);
+          if (mode == 0)
+            buf[e] = vec[o];
+          else if (mode == 1)
+            vec[o] = buf[e];
+          else if (mode == 2)
+            vec[o] += buf[e];
+          else
+            vec[o] = 0.;
+        }
+    }
+  } // namespace
+
+  void
+  vec_residual(double *r, const double *b, long long n, hipStream_t st)
+  {
+    launch2(n, ResidualOp{(double2 *)r, (const double2 *)b}, st);
+  }
+  void
+  vec_scale(double *y, const double *x, double a, long long n, hipStream_t st)
+  {
+    launch2(n, ScaleOp{(double2 *)y, (const double2 *)x, a}, st);
+  }
+  void
+  vec_mul(double *y, const double *x, const double *d, long long n, hipStream_t st)
+  {
+    launch2(n, MulOp{(double2 *)y, (const double2 *)x, (const double2 *)d}, st);
+  }
+  void
+  vec_axpby(double *y, double a, const double *x, double b, long long n, hipStream_t st)
+  {
+    launch2(n, AxpbyOp{(double2 *)y, (const double2 *)x, a, b}, st);
+  }
+  void
+  vec_cheb_update(double *y, const double *x, const double *xo, const double *t, double f1, double f2, long long n,
+                  hipStream_t st)
+  {
+    launch2(n, ChebOp{(double2 *)y, (const double2 *)x, (const double2 *)xo, (const double2 *)t, f1, f2}, st);
+  }
+  void
+  vec_invert_diagonal(double *d, long long n, hipStream_t st)
+  {
+    launch2(n, InvDiagOp{(double2 *)d}, st);
+  }
+  void
+  vec_dot(const DevGrid &g, const double *x, const double *y, double *result, hipStream_t st)
+  {
+    const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+    hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n, 8)), dim3(VB), 0, st, g, x, y, result);
+  }
+  void
+  vec_initial_guess(const DevGrid &g, double *v, const long long gbegin[3], const long long gsize[3], hipStream_t st)
+  {
+    const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+    hipLaunchKernelGGL(initial_guess_kernel, dim3(grid_for(n, 4)), dim3(VB), 0, st, g, v, gbegin[0], gbegin[1], gbegin[2],
+                       gsize[0], gsize[1]);
+  }
+  void
+  vec_add_scalar_owned(const DevGrid &g, double *v, double a, hipStream_t st)
+  {
+    const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+    hipLaunchKernelGGL(add_scalar_owned_kernel, dim3(grid_for(n, 4)), dim3(VB), 0, st, g, v, a);
+  }
+  void
+  vec_constrained(const DevGrid &g, int mode, double *dst, const double *src, const double *b, hipStream_t st)
+  {
+    bool any = false;
+    for (int d = 0; d < 3; ++d)
+      any = any || g.dir_lo[d] || g.dir_hi[d];
+    if (!any)
+      return;
+    hipLaunchKernelGGL(constrained_kernel, dim3(64, 6), dim3(VB), 0, st, g, mode, dst, src, b);
+  }
+  void
+  vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st)
+  {
+    const long long n = (long long)size[0] * size[1] * size[2];
+    if (n <= 0)
+      return;
+    hipLaunchKernelGGL(box_kernel, dim3(grid_for(n, 4)), dim3(VB), 0, st, g, mode, vec, buf, lo[0], lo[1], lo[2], size[0],
+                       size[1], size[2]);
+  }
+} // namespace asmamd

@@ -1,0 +1,235 @@
+/*
+ * dealii_asm_amd.h -- C ABI of the MI355X-native matrix-free Laplace operator and
+ * FDM additive-Schwarz / Chebyshev smoother (libdealii_asm_amd.so).
+ *
+ * Every entry point names the reference interface (peterrum/dealii-asm, paths
+ * relative to the reference root) it replaces.  The reference has no FFI of its
+ * own: its components are glued by C++ templates, so the
+ * "binding" a maintainer adds is the thin C++ shim in dealii_asm_amd.hpp, shown
+ * in INTEGRATION.md.
+ *
+ * Conventions
+ *  - all vectors are DEVICE pointers to double, laid out as described by
+ *    asm_vector_layout() (a lexicographic box, x fastest, with optional ghost
+ *    planes and a padded row pitch); the caller owns them;
+ *  - all calls are asynchronous on the stream given at creation unless stated;
+ *    one in-flight call per context (the reference's operators hold mutable
+ *    scratch and are not re-entrant either: include/matrix_free.h:1545-1564);
+ *  - return value 0 = success, otherwise an ASM_ERR_* code; asm_last_error()
+ *    returns the message (the reference throws C++ exceptions instead:
+ *    include/precondition.templates.h:26,79-81,815).
+ */
+#ifndef DEALII_ASM_AMD_H
+#define DEALII_ASM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct asm_ctx asm_ctx;
+
+enum asm_status
+{
+  ASM_OK                = 0,
+  ASM_ERR_INVALID_VALUE = 1,
+  ASM_ERR_NOT_SUPPORTED = 2, /* mirrors ExcNotImplemented() in the reference */
+  ASM_ERR_DEVICE        = 3, /* HIP / RCCL runtime error */
+  ASM_ERR_NO_DEVICE     = 4  /* no HIP device: the product path never falls back to the CPU */
+};
+
+/* boundary type of one face of the global box (include/matrix_free.h:350-360
+ * passes boundary id {1} as Dirichlet, {2} as Neumann; periodic faces come from
+ * matrix_free_loop_08.likwid.cc:163-169) */
+enum asm_boundary
+{
+  ASM_BC_PERIODIC  = 0,
+  ASM_BC_DIRICHLET = 1,
+  ASM_BC_NEUMANN   = 2
+};
+
+/* Restrictors::WeightingType, include/restrictors.h:8-15 (same order) */
+enum asm_weighting
+{
+  ASM_W_NONE = 0,
+  ASM_W_PRE  = 1,
+  ASM_W_POST = 2,
+  ASM_W_RAS  = 3,
+  ASM_W_SYMM = 4
+};
+
+/* mesh generators of the reference drivers */
+enum asm_geometry
+{
+  ASM_GEOM_CARTESIAN = 0, /* subdivided box, matrix_free_loop_08.likwid.cc:160-174 */
+  ASM_GEOM_KERSHAW   = 1, /* include/kershaw.h:39-80 via MappingQCache(2),
+                             element_centered_preconditioners_01.cc:352-424 */
+  ASM_GEOM_Q2_POINTS = 2  /* caller supplies the 27 mapping support points per cell */
+};
+
+/* "type" of the inner preconditioner of the Chebyshev smoother,
+ * include/precondition.templates.h:481-573 */
+enum asm_preconditioner
+{
+  ASM_PRECOND_FDM      = 0,
+  ASM_PRECOND_DIAGONAL = 1
+};
+
+/* "ev algorithm", include/precondition.templates.h:113-133 */
+enum asm_ev_algorithm
+{
+  ASM_EV_AUTO            = 0, /* lanczos if symmetric else power iteration */
+  ASM_EV_LANCZOS         = 1,
+  ASM_EV_POWER_ITERATION = 2
+};
+
+/* kernel family used for the sweeps */
+enum asm_kernel_variant
+{
+  ASM_KERNEL_AUTO    = 0,
+  ASM_KERNEL_GENERIC = 1, /* one patch per thread group, scatter-add with fp64 atomics */
+  ASM_KERNEL_TILED   = 2  /* owner-computes tiles, fused Chebyshev updates, no atomics */
+};
+
+typedef struct asm_params
+{
+  /* --- discretisation ------------------------------------------------- */
+  int32_t degree;         /* FE_Q(p), 1 <= p <= 7 ("degree") */
+  int32_t n_cells[3];     /* GLOBAL number of cells per direction */
+  int32_t boundary[3][2]; /* asm_boundary of the low/high face per direction */
+  int32_t geometry;       /* asm_geometry */
+  double  extent[3];      /* edge lengths of the (undeformed) box */
+  double  kershaw_eps[2]; /* eps_y, eps_z ("mesh.eps") */
+  const double *q2_points; /* ASM_GEOM_Q2_POINTS: host array [cell][27][3], cells x-fastest */
+
+  /* --- FDM preconditioner: keys of create_fdm_preconditioner,
+   *     include/precondition.templates.h:195-211 ------------------------ */
+  int32_t precond_type;     /* asm_preconditioner */
+  int32_t n_overlap;        /* "n overlap", default 1, clamped to p */
+  int32_t weighting_type;   /* "weighting type" */
+  int32_t element_centric;  /* "element centric": 1 = cell patches, 0 = vertex-star */
+
+  /* --- Chebyshev: create_chebyshev_preconditioner,
+   *     include/precondition.templates.h:108-152 ------------------------ */
+  int32_t cheb_degree;      /* "degree", default 3 */
+  double  smoothing_range;  /* "smoothing range", default 20 */
+  int32_t eig_n_iterations; /* eig_cg_n_iterations, 40 in the reference */
+  int32_t ev_algorithm;     /* asm_ev_algorithm */
+
+  /* --- execution ------------------------------------------------------- */
+  int32_t kernel_variant; /* asm_kernel_variant */
+  int32_t device;         /* HIP device ordinal, -1 = current */
+  void   *stream;         /* hipStream_t, NULL = default stream */
+
+  /* --- domain decomposition (one process per GPU) ---------------------- */
+  int32_t rank;
+  int32_t world_size;
+  int32_t proc_grid[3]; /* ranks per direction, product == world_size; 0 = choose */
+} asm_params;
+
+/* description of the device vector layout (replaces
+ * LinearAlgebra::distributed::Vector + Utilities::MPI::Partitioner as used in
+ * include/operator.h:1491-1498 and include/matrix_free.h:994-998) */
+typedef struct asm_layout
+{
+  int64_t n_global_dofs; /* LaplaceOperatorMatrixFree::m(), include/operator.h:767-771 */
+  int64_t n_owned;       /* locally owned DoFs */
+  int64_t n_ghost;       /* stored entries owned by another rank (or periodic images) */
+  int64_t n_alloc;       /* doubles to allocate per vector (includes row padding) */
+  int32_t owned_begin[3]; /* first owned DoF plane, GLOBAL logical coordinate */
+  int32_t owned_size[3];  /* owned DoF planes per direction */
+  int32_t store_begin[3]; /* first stored plane, LOCAL logical coordinate (<= 0) */
+  int32_t store_size[3];  /* stored planes per direction */
+  int64_t stride[3];      /* element strides of the box */
+  int32_t cell_begin[3];  /* first local cell, global cell coordinate */
+  int32_t cell_size[3];   /* local cells per direction */
+  int32_t proc_grid[3];
+  int32_t proc_coord[3];
+} asm_layout;
+
+/* ----- life cycle ------------------------------------------------------- */
+
+/* fills *p with the reference's defaults */
+void asm_params_default(asm_params *p);
+
+/* ASPoissonPreconditioner::ASPoissonPreconditioner (include/matrix_free.h:73-894),
+ * LaplaceOperatorMatrixFree::setup_mapping_and_indices (include/operator.h:490-753)
+ * and create_chebyshev_preconditioner without the eigenvalue estimate. */
+int asm_create(const asm_params *p, asm_ctx **out);
+void asm_destroy(asm_ctx *ctx);
+const char *asm_last_error(const asm_ctx *ctx); /* ctx may be NULL: last creation error */
+
+/* host-only description of what rank `rank` would own; needs no GPU
+ * (used by the multi-process CPU tests) */
+int asm_describe_layout(const asm_params *p, asm_layout *out);
+
+/* RCCL bootstrap: rank 0 fills a 128-byte id, the host broadcasts it, every rank
+ * joins.  Replaces the MPI communicator held by deal.II's Partitioner. */
+int asm_comm_unique_id(char id[128]);
+int asm_comm_init(asm_ctx *ctx, const char id[128]);
+
+/* ----- vectors ---------------------------------------------------------- */
+
+int asm_vector_layout(const asm_ctx *ctx, asm_layout *out);
+/* initialize_dof_vector (include/operator.h:1491-1498): allocates and zeroes */
+int asm_vector_alloc(asm_ctx *ctx, double **v);
+int asm_vector_free(asm_ctx *ctx, double *v);
+/* copy between a HOST array holding this rank's owned DoFs in lexicographic
+ * order (x fastest, owned_size box) and a device vector (synchronous) */
+int asm_vector_import(asm_ctx *ctx, double *dev, const double *host_owned);
+int asm_vector_export(asm_ctx *ctx, double *host_owned, const double *dev);
+/* VectorDataExchange::update_ghost_values_start/finish
+ * (include/matrix_free_internal.h:13-47) */
+int asm_update_ghost_values(asm_ctx *ctx, double *v);
+/* compress_start/finish with VectorOperation::add + zero_out_ghost_values
+ * (include/matrix_free_internal.h:49-103) */
+int asm_compress_add(asm_ctx *ctx, double *v);
+
+/* ----- operators -------------------------------------------------------- */
+
+/* LaplaceOperatorMatrixFree::vmult(dst, src), include/operator.h:1353-1365 */
+int asm_op_vmult(asm_ctx *ctx, double *dst, const double *src);
+/* LaplaceOperatorMatrixFree::compute_inverse_diagonal, include/operator.h:1512-1524 */
+int asm_op_inverse_diagonal(asm_ctx *ctx, double *out);
+/* ASPoissonPreconditioner::vmult(dst, src), include/matrix_free.h:925-954
+ * (or DiagonalMatrix::vmult when precond_type == ASM_PRECOND_DIAGONAL) */
+int asm_precond_vmult(asm_ctx *ctx, double *dst, const double *src);
+
+/* PreconditionChebyshev::estimate_eigenvalues as driven by
+ * include/precondition.templates.h:458-463; synchronous.  Returns the
+ * largest-eigenvalue estimate (before the 1.2 safety factor). */
+int asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max);
+/* install an eigenvalue estimate obtained elsewhere */
+int asm_cheb_set_eigenvalue(asm_ctx *ctx, double lambda_max);
+/* PreconditionerBase::vmult / step as reached through PreconditionerAdapter
+ * (include/preconditioners.h:725-742, 897-926) and WrapperForGMG
+ * (include/precondition.h:24-78): dst = p_k(P^-1 A) P^-1 src with a zero
+ * (vmult) or the given (step) initial guess in dst. */
+int asm_cheb_vmult(asm_ctx *ctx, double *dst, const double *src);
+int asm_cheb_step(asm_ctx *ctx, double *dst, const double *src);
+
+/* ----- queries ---------------------------------------------------------- */
+
+/* ASPoissonPreconditioner::n_fdm_instances, include/matrix_free.h:1000-1004
+ * (number of distinct 1-D eigen-decompositions stored) */
+int asm_n_fdm_instances(const asm_ctx *ctx, int64_t *n);
+/* ASPoissonPreconditioner::memory_consumption, include/matrix_free.h:988-992
+ * (bytes of per-cell / per-instance device data of operator + preconditioner) */
+int asm_memory_consumption(const asm_ctx *ctx, int64_t *bytes);
+/* theta, delta, lambda_max of the Chebyshev polynomial in use */
+int asm_cheb_parameters(const asm_ctx *ctx, double out[3]);
+/* kernel variant actually selected (asm_kernel_variant) */
+int asm_kernel_variant_in_use(const asm_ctx *ctx, int32_t *variant);
+/* hipStreamSynchronize on the context's stream */
+int asm_synchronize(asm_ctx *ctx);
+/* timing helper for benchmarks: runs `reps` back-to-back calls of one entry
+ * point between two HIP events on the context's stream and returns the
+ * elapsed milliseconds.  what: 0 op_vmult, 1 precond_vmult, 2 cheb_vmult, 3 cheb_step */
+int asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEALII_ASM_AMD_H */
