@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one Chebyshev-wrapped FDM additive-Schwarz smoother
+application (PreconditionChebyshev::step, as timed by the reference harness
+matrix_free_loop_08.likwid.cc:345-395), 3-D, p=4, on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU;
+the mesh is block-decomposed (weak scaling: every rank keeps `--cells` cells) and
+ghost planes travel over RCCL inside the library.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+  cart_dirichlet  Cartesian box, all faces Dirichlet (experiments/amd-opt_fdm1_cart.json:
+                  Kershaw generator with eps=1), default 80^3 cells/GPU = 33 076 161 DoFs
+  cart_periodic   periodic box of the reference harness (matrix_free_loop_08.likwid.cc:160-174)
+  kershaw         Kershaw eps=0.3 (experiments/large-scaling-opt_fdm1.json), Q2 geometry
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_dof(degree, what):
+    """fp64 vector bytes per DoF that one smoother application must move (SURVEY.md 8d,
+    metadata excluded: this implementation stores no index lists).
+      A residual sweep: read x, read b, write r           = 24
+      P sweep, first (x0 = 0): read b, write x            = 16
+      P sweep after a residual: read r, x(, x_old), write = 24 / 32
+    """
+    a_sweep = 24.0
+    if what == "cheb_vmult":
+        p_sweeps = [16.0] + [24.0 if j == 1 else 32.0 for j in range(1, degree)]
+        a_sweeps = [a_sweep] * (degree - 1)
+    else:
+        p_sweeps = [24.0] + [32.0] * (degree - 1)
+        a_sweeps = [a_sweep] * degree
+    return a_sweeps, p_sweeps
+
+
+def cpu_baseline(args, pkg):
+    """numpy restatement (oracle/asm_oracle.py, kind 'port') of the same smoother
+    application, timed on one host core on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import asm_oracle as orc
+
+    nc = (12, 12, 12)
+    bc = orc.PERIODIC if args.workload == "cart_periodic" else orc.DIRICHLET
+    mapfn = (lambda pts: orc.kershaw(0.3, 0.3, pts)) if args.workload == "kershaw" else None
+    mesh = orc.Mesh(nc, 4, [bc] * 3, mapfn=mapfn)
+    op = orc.LaplaceOperator(mesh)
+    prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
+    cheb = orc.Chebyshev(op, prec, degree=args.degree, lambda_max=1.8)
+    b = np.ones(mesh.n_dofs)
+    x = np.zeros(mesh.n_dofs)
+    x = cheb.step(x, b)  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        x = cheb.step(x, b)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 50:
+            break
+    return {
+        "value": mesh.n_dofs * reps / el,
+        "unit": "DoF/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} cells p=4 "
+        f"({mesh.n_dofs} DoFs), numpy oracle, 1 thread",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cart_dirichlet", choices=["cart_dirichlet", "cart_periodic", "kershaw"])
+    ap.add_argument("--cells", type=int, nargs=3, default=None, help="cells per GPU")
+    ap.add_argument("--degree", type=int, default=1, help="Chebyshev degree (amd-opt_fdm1_cart.json: 1)")
+    ap.add_argument("--what", default="cheb_step", choices=["cheb_step", "cheb_vmult"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    pkg = load_package()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cells = args.cells
+    if cells is None:
+        cells = {"cart_dirichlet": (80, 80, 80), "cart_periodic": (128, 64, 64), "kershaw": (78, 78, 78)}[args.workload]
+    # weak scaling: the library splits z first, then y, then x
+    probe = pkg.make_params(n_cells=(64, 64, 64), world_size=world, rank=rank)
+    grid = list(pkg.describe_layout(probe).proc_grid)
+    n_cells = [cells[d] * grid[d] for d in range(3)]
+    boundary = "periodic" if args.workload == "cart_periodic" else "dirichlet"
+    geometry = "kershaw" if args.workload == "kershaw" else "cartesian"
+    extent = (float(n_cells[0]) / n_cells[2], float(n_cells[1]) / n_cells[2], 1.0) if geometry == "cartesian" else (1.0, 1.0, 1.0)
+    ctx = pkg.Context(
+        degree=4,
+        n_cells=n_cells,
+        boundary=boundary,
+        geometry=geometry,
+        kershaw_eps=(0.3, 0.3),
+        extent=extent,
+        precond="FDM",
+        n_overlap=1,
+        weighting="post",
+        cheb_degree=args.degree,
+        kernel=args.kernel,
+        device=local_rank,
+        rank=rank,
+        world_size=world,
+        proc_grid=grid,
+    )
+    if world > 1:
+        import torch
+
+        uid = [pkg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0])
+
+    def barrier():
+        ctx.synchronize()
+        if world > 1:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    n_dofs = ctx.n_dofs
+    b = ctx.vector(np.ones(ctx.n_owned))  # src = 1.0, matrix_free_loop_08.likwid.cc:304
+    x = ctx.vector()
+    lam = ctx.estimate_eigenvalues()  # setup, not timed (precondition.templates.h:461-463)
+    run = {"cheb_step": ctx.cheb_step, "cheb_vmult": ctx.cheb_vmult}[args.what]
+    for _ in range(args.warmup):
+        run(x, b)
+    barrier()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run(x, b)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = {k: ctx.profile_get(k) for k in ("laplace", "fdm")}
+    ctx.profile_enable(False)
+    if world > 1:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        a_sw, p_sw = algorithmic_bytes_per_dof(args.degree, args.what)
+        # dominant kernel = the one with the larger total time
+        kernels = {}
+        for name, sweeps in (("laplace", a_sw), ("fdm", p_sw)):
+            n, ms = prof[name]
+            if n:
+                bytes_per_launch = float(np.mean(sweeps)) * ctx.n_owned
+                kernels[name] = {
+                    "launches": n,
+                    "avg_ms": ms / n,
+                    "bytes_per_launch": bytes_per_launch,
+                    "GBps": bytes_per_launch / (ms / n * 1e-3) / 1e9,
+                }
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+        roofline = {
+            "bound": "hbm",
+            "kernel": {"laplace": "Laplace sweep", "fdm": "FDM Schwarz sweep"}[dom] + f" ({ctx.kernel_variant()})",
+            "achieved": kernels[dom]["GBps"],
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_ms": kernels[dom]["avg_ms"],
+            "kernels": kernels,
+        }
+        total_bytes = (sum(a_sw) + sum(p_sw)) * n_dofs
+        out = {
+            "metric": "DoF/s per smoother application (Cheby+FDM, p=4, 3D)",
+            "value": n_dofs * args.steps / elapsed,
+            "unit": "DoF/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload} p=4 {n_cells[0]}x{n_cells[1]}x{n_cells[2]} cells, "
+                f"Chebyshev degree {args.degree} {args.what.split('_')[1]}(), FDM n_overlap=1 post weights",
+                "n_dofs": n_dofs,
+                "cells_per_gpu": list(cells),
+                "proc_grid": grid,
+                "kernel_variant": ctx.kernel_variant(),
+                "lambda_max_estimate": lam,
+            },
+            "application_bytes_per_dof": (sum(a_sw) + sum(p_sw)),
+            "application_hbm_frac": total_bytes / world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, pkg)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

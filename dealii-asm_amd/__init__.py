@@ -99,6 +99,8 @@ EXPORTED_SYMBOLS = [
     "asm_kernel_variant_in_use",
     "asm_synchronize",
     "asm_time_calls",
+    "asm_profile_enable",
+    "asm_profile_get",
 ]
 
 _lib = None
@@ -140,6 +142,8 @@ def load_library():
     lib.asm_kernel_variant_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_synchronize.argtypes = [C.c_void_p]
     lib.asm_time_calls.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.asm_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.asm_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.asm_comm_unique_id.argtypes = [C.c_char_p]
     lib.asm_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     _lib = lib
@@ -348,6 +352,15 @@ class Context:
         ms = C.c_float()
         self._check(self.lib.asm_time_calls(self.handle, idx, reps, dst.ptr, src.ptr, C.byref(ms)))
         return ms.value
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.asm_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_get(self, kernel):
+        """(launches, total ms) of kernel 'laplace' or 'fdm' since profile_enable"""
+        n, ms = C.c_int64(), C.c_double()
+        self._check(self.lib.asm_profile_get(self.handle, {"laplace": 0, "fdm": 1}[kernel], C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def comm_init(self, unique_id: bytes):
         self._check(self.lib.asm_comm_init(self.handle, unique_id))

@@ -41,6 +41,10 @@ struct asm_ctx
   ncclComm_t               comm       = nullptr;
   double *                 hbuf[4]    = {nullptr, nullptr, nullptr, nullptr}; // send lo/hi, recv lo/hi
   long long                hbuf_size  = 0;
+  // optional per-kernel timing with HIP events on the context's stream
+  bool                                           profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[2];
+  size_t                                         prof_used[2] = {0, 0};
   std::string              error;
 };
 
@@ -98,6 +102,31 @@ namespace
   multi_rank(const asm_ctx *ctx)
   {
     return ctx->s.prm.world_size > 1;
+  }
+
+  // kernel ids: 0 = Laplace sweep kernel, 1 = FDM sweep kernel
+  void
+  prof_mark(asm_ctx *ctx, const int id, const bool begin)
+  {
+    if (!ctx->profile)
+      return;
+    auto &ev = ctx->prof_events[id];
+    if (begin)
+      {
+        if (ctx->prof_used[id] == ev.size())
+          {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+              return;
+            ev.emplace_back(a, b);
+          }
+        (void)hipEventRecord(ev[ctx->prof_used[id]].first, ctx->stream);
+      }
+    else if (ctx->prof_used[id] < ev.size())
+      {
+        (void)hipEventRecord(ev[ctx->prof_used[id]].second, ctx->stream);
+        ++ctx->prof_used[id];
+      }
   }
 
   // ---- ghost exchange ----------------------------------------------------
@@ -237,7 +266,10 @@ namespace
     if (ctx->s.kernel == ASM_KERNEL_TILED)
       {
         TiledArgs a{mode, src, dst, b, nullptr, nullptr, 0., 0.};
-        if (!laplace_tiled(ctx->g, ctx->op, a, ctx->stream))
+        prof_mark(ctx, 0, true);
+        const bool ok = laplace_tiled(ctx->g, ctx->op, a, ctx->stream);
+        prof_mark(ctx, 0, false);
+        if (!ok)
           {
             ctx->error = "tiled Laplace kernel not available for this configuration";
             return ASM_ERR_NOT_SUPPORTED;
@@ -245,7 +277,10 @@ namespace
         return ASM_OK;
       }
     HIP_TRY(hipMemsetAsync(dst, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
-    if (!laplace_generic(ctx->g, ctx->op, src, dst, false, ctx->stream))
+    prof_mark(ctx, 0, true);
+    const bool ok = laplace_generic(ctx->g, ctx->op, src, dst, false, ctx->stream);
+    prof_mark(ctx, 0, false);
+    if (!ok)
       {
         ctx->error = "generic Laplace kernel not available for this degree";
         return ASM_ERR_NOT_SUPPORTED;
@@ -289,7 +324,10 @@ namespace
     if (ctx->s.kernel == ASM_KERNEL_TILED)
       {
         TiledArgs a{mode, src, dst, nullptr, x, x_old, f1, f2};
-        if (!fdm_tiled(ctx->g, ctx->f, a, ctx->stream))
+        prof_mark(ctx, 1, true);
+        const bool ok = fdm_tiled(ctx->g, ctx->f, a, ctx->stream);
+        prof_mark(ctx, 1, false);
+        if (!ok)
           {
             ctx->error = "tiled FDM kernel not available for this configuration";
             return ASM_ERR_NOT_SUPPORTED;
@@ -298,7 +336,10 @@ namespace
       }
     double *t = (mode == PC_PLAIN) ? dst : ctx->T;
     HIP_TRY(hipMemsetAsync(t, 0, n * sizeof(double), ctx->stream));
-    if (!fdm_generic(ctx->g, ctx->f, src, t, ctx->stream))
+    prof_mark(ctx, 1, true);
+    const bool ok = fdm_generic(ctx->g, ctx->f, src, t, ctx->stream);
+    prof_mark(ctx, 1, false);
+    if (!ok)
       {
         ctx->error = "generic FDM kernel not available for this patch size";
         return ASM_ERR_NOT_SUPPORTED;
@@ -598,6 +639,12 @@ asm_destroy(asm_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm)
     ncclCommDestroy(ctx->comm);
+  for (int k = 0; k < 2; ++k)
+    for (auto &e : ctx->prof_events[k])
+      {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+      }
   for (void *q : ctx->allocs)
     (void)hipFree(q);
   if (ctx->h_scalar)
@@ -889,6 +936,35 @@ int
 asm_synchronize(asm_ctx *ctx)
 {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ASM_OK;
+}
+
+int
+asm_profile_enable(asm_ctx *ctx, int on)
+{
+  ctx->profile      = on != 0;
+  ctx->prof_used[0] = ctx->prof_used[1] = 0;
+  return ASM_OK;
+}
+
+int
+asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms)
+{
+  if (kernel < 0 || kernel > 1)
+    {
+      ctx->error = "asm_profile_get: kernel must be 0 (Laplace sweep) or 1 (FDM sweep)";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  double sum = 0.;
+  for (size_t i = 0; i < ctx->prof_used[kernel]; ++i)
+    {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_events[kernel][i].first, ctx->prof_events[kernel][i].second));
+      sum += ms;
+    }
+  *launches = (int64_t)ctx->prof_used[kernel];
+  *total_ms = sum;
   return ASM_OK;
 }
 

@@ -224,6 +224,12 @@ int asm_cheb_parameters(const asm_ctx *ctx, double out[3]);
 int asm_kernel_variant_in_use(const asm_ctx *ctx, int32_t *variant);
 /* hipStreamSynchronize on the context's stream */
 int asm_synchronize(asm_ctx *ctx);
+/* per-kernel timing for the roofline report: while enabled, every launch of the
+ * Laplace sweep kernel (kernel 0) and of the FDM sweep kernel (kernel 1) is
+ * bracketed by HIP events on the context's stream (the LIKWID marker regions of
+ * matrix_free_loop_08.likwid.cc:365-377 are the reference's counterpart) */
+int asm_profile_enable(asm_ctx *ctx, int on);
+int asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
 /* timing helper for benchmarks: runs `reps` back-to-back calls of one entry
  * point between two HIP events on the context's stream and returns the
  * elapsed milliseconds.  what: 0 op_vmult, 1 precond_vmult, 2 cheb_vmult, 3 cheb_step */
