@@ -119,3 +119,50 @@ def test_chebyshev(pkg, nc, p, bc, weighting, precond, degree):
         xv.set(x0)
         ctx.cheb_step(xv, bv)
         assert rel(xv.get(), cheb.step(x0, b)) < TOL
+
+
+# ---------------------------------------------------------------------------
+# tiled owner-computes kernels (degree 4, n_overlap 1): same oracle, same tolerance
+# ---------------------------------------------------------------------------
+TILED_CASES = [
+    ((3, 2, 2), "periodic", "cartesian"),
+    ((3, 3, 2), "dirichlet", "cartesian"),
+    ((17, 4, 3), ["dirichlet", "periodic", "neumann"], "cartesian"),
+    ((4, 16, 5), ["periodic", "dirichlet", "dirichlet"], "cartesian"),
+    ((6, 2, 2), "dirichlet", "kershaw"),
+    ((18, 16, 2), "dirichlet", "kershaw"),
+]
+
+
+@pytest.mark.parametrize("weighting", ["none", "pre", "post", "symm", "ras"])
+@pytest.mark.parametrize("nc,bc,geometry", TILED_CASES)
+def test_precond_vmult_tiled(pkg, nc, bc, geometry, weighting):
+    mesh, ctx = make_pair(pkg, nc, 4, bc, geometry, eps=(0.3, 0.3), kernel="tiled", weighting=weighting)
+    with ctx:
+        assert ctx.kernel_variant() == "tiled"
+        rng = np.random.default_rng(7)
+        src = rng.uniform(-1, 1, mesh.n_dofs)
+        ref = orc.ASPoissonPreconditioner(mesh, 1, weighting).vmult(src)
+        x, y = ctx.vector(src), ctx.vector(np.full(mesh.n_dofs, 123.0))  # dst needs no zeroing
+        ctx.precond_vmult(y, x)
+        assert rel(y.get(), ref) < TOL
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4])
+@pytest.mark.parametrize("nc,bc,geometry", TILED_CASES[:5])
+def test_chebyshev_tiled(pkg, nc, bc, geometry, degree):
+    mesh, ctx = make_pair(pkg, nc, 4, bc, geometry, eps=(0.3, 0.3), kernel="tiled", weighting="post", cheb_degree=degree)
+    with ctx:
+        op = orc.LaplaceOperator(mesh)
+        prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
+        cheb = orc.Chebyshev(op, prec, degree=degree, lambda_max=1.9)
+        ctx.set_eigenvalue(1.9)
+        rng = np.random.default_rng(11)
+        b = rng.uniform(-1, 1, mesh.n_dofs)
+        x0 = rng.uniform(-1, 1, mesh.n_dofs)
+        bv, xv = ctx.vector(b), ctx.vector()
+        ctx.cheb_vmult(xv, bv)
+        assert rel(xv.get(), cheb.vmult(b)) < TOL
+        xv.set(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), cheb.step(x0, b)) < TOL
