@@ -582,6 +582,24 @@ asm_create(const asm_params *p, asm_ctx **out)
           UP(s.w_post[d], &f.w_post[d]);
         }
       UP(s.eig, &f.eig);
+      f.n_inst   = s.n_inst;
+      f.has_pre  = s.has_pre;
+      f.has_post = s.has_post;
+      if (s.tensor_inst && s.n_inst <= 8)
+        {
+          // reciprocal eigenvalue sums of every instance triple (a few hundred KB, cache resident)
+          const int           m = s.m, E = m * m + m, n = s.n_inst;
+          std::vector<double> inv((size_t)n * n * n * m * m * m);
+          for (int iz = 0; iz < n; ++iz)
+            for (int iy = 0; iy < n; ++iy)
+              for (int ix = 0; ix < n; ++ix)
+                for (int c = 0; c < m; ++c)
+                  for (int b = 0; b < m; ++b)
+                    for (int a = 0; a < m; ++a)
+                      inv[(((size_t)(iz * n + iy) * n + ix) * m + c) * m * m + b * m + a] =
+                        1.0 / (s.eig[(size_t)ix * E + m * m + a] + (s.eig[(size_t)iy * E + m * m + b] + s.eig[(size_t)iz * E + m * m + c]));
+          UP(inv, &f.inv_table);
+        }
     }
 #undef UP
   if (alloc_vec(ctx, &ctx->R) || alloc_vec(ctx, &ctx->T) || alloc_vec(ctx, &ctx->S))

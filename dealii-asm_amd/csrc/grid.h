@@ -78,6 +78,10 @@ namespace asmamd
     int tensor_inst;       // 1: instance id depends on (d, c_d) only
     const int *inst[3];    // [nc[d]] (tensor) or [ncells] (per cell): instance id of direction d
     const double *eig;     // [n_inst][m*m + m]: Q (row i, col a) then lambda
+    int           n_inst;
+    int           has_pre, has_post; // weights differ from the 0/1 validity mask
+    // tensor-product meshes: 1/(lx+ly+lz) for every instance triple, [iz][iy][ix][m^3], or nullptr
+    const double *inv_table;
     const double *w_pre[3];  // [nc[d]][m] 1-D factors of the pre weight, or nullptr
     const double *w_post[3]; // [nc[d]][m] 1-D factors of the post weight, or nullptr
   };
