@@ -564,6 +564,8 @@ asm_create(const asm_params *p, asm_ctx **out)
   UP(ctx->basis->Dc, &op.Dc);
   UP(ctx->basis->xq, &op.xq);
   UP(ctx->basis->wq, &op.wq);
+  UP(ctx->basis->M_ref, &op.M_ref);
+  UP(ctx->basis->K_ref, &op.K_ref);
   // FDM data
   DevFdm &f = ctx->f;
   std::memset(&f, 0, sizeof(f));

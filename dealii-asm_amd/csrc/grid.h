@@ -96,5 +96,7 @@ namespace asmamd
     const double *Dc;     // [q][r]
     const double *xq;     // [q]
     const double *wq;     // [q]
+    const double *M_ref;  // [i][j] reference mass matrix of FE_Q<1>(p) on [0,1]
+    const double *K_ref;  // [i][j] reference stiffness matrix
   };
 } // namespace asmamd

@@ -1,20 +1,25 @@
 // Tiled owner-computes sweeps for degree 4, cell patches with n_overlap = 1 (gfx950).
 //
-// One workgroup (4 waves, one per SIMD) owns a tile of 15 x 15 cells' worth of DoFs
-// in x-y and marches along z.  It computes 16 x 16 cells per layer (one halo row /
-// column on the low sides), ONE CELL PER LANE, the whole 5x5x5 patch tile living in
-// that lane's registers, so the 1-D eigenvector sweeps (TensorProductMatrix-
-// SymmetricSum::apply_inverse as called at include/matrix_free.h:1046-1052) are pure
-// register FMA chains with no LDS traffic.  LDS is used only to
-//   * stage one (65 x 65) DoF plane of src at a time, read coalesced from HBM and
-//     scattered to the cells that contain each DoF (the gather of
-//     include/vector_access_reduced.h:267-405 without any index list), and
-//   * exchange the cells' output planes, which the DoF owners sum in a fixed order
-//     (the scatter-add of :407-548 without atomics, bitwise reproducible).
-// Every owned DoF is written exactly once, by one thread that holds its final
-// value, so the Chebyshev vector updates that the reference passes as pre/post
-// lambdas (include/matrix_free.h:960-986, PreconditionChebyshev) are applied in the
-// store epilogue and dst needs no zeroing, no compress(add) and no atomics.
+// Work decomposition
+//   * a workgroup (8 waves = 512 threads) owns the DoFs of 11 x 7 cells in x-y and
+//     marches along z over a chunk of cell layers; per layer it computes 12 x 8
+//     cells (one halo column / row on the low sides, so that every owned DoF sees
+//     all the cells that contribute to it);
+//   * wave w handles cell row w of the tile: 12 cells x 5 lanes, lane (cell, k)
+//     holds one 5 x 5 plane of the cell's 5 x 5 x 5 patch tile in registers;
+//   * the two in-plane 1-D sweeps run on registers, the third direction is reached
+//     by a 5-lane transpose through a small wave-private LDS buffer (no workgroup
+//     barrier involved);
+//   * the cells' output planes are summed into four LDS DoF planes (even cell rows,
+//     barrier, odd cell rows, so that the order of the additions is fixed), the
+//     z-neighbour's share travels from layer to layer through a wave-private LDS
+//     carry, and the owner thread of every DoF applies the fused vector update and
+//     stores it once, coalesced.
+// This replaces, for the headline configuration, the gather / apply_inverse /
+// scatter-add of ASPoissonPreconditioner::vmult_internal (include/matrix_free.h:
+// 1023-1062), the cell loop of LaplaceOperatorMatrixFree::vmult (include/operator.h:
+// 1367-1430) and the pre/post lambdas PreconditionChebyshev hands to both: dst needs
+// no zeroing, no atomics on HBM and no compress(add); results are bitwise reproducible.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -32,12 +37,21 @@ namespace asmamd
     constexpr int P   = 4;
     constexpr int N1  = 5;
     constexpr int NE  = 25;       // values per cell plane
-    constexpr int TC  = 16;       // computed cells per tile and direction
-    constexpr int TO  = TC - 1;   // owned cells per tile and direction
-    constexpr int NT  = TC * TC;  // threads = cells per layer
-    constexpr int SP  = NT + 4;   // staging pitch (bank spread for the 4-lane cell groups)
-    constexpr int NR  = 17;       // rows handled by one loader thread (rows wave + 4 r)
+    constexpr int WX  = 12;       // cells per wave (x)
+    constexpr int TY  = 8;        // cell rows per tile = waves per workgroup
+    constexpr int OX  = WX - 1;   // owned cells per tile, x
+    constexpr int OY  = TY - 1;   // owned cells per tile, y
+    constexpr int NT  = TY * 64;  // threads
+    constexpr int PX  = P * WX + 1; // DoFs per tile row (49)
+    constexpr int PY  = P * TY + 1; // DoF rows per tile (33)
+    constexpr int NR  = 5;        // rows per epilogue thread: Jr = wave + 8 r
     constexpr int EIG = NE + N1;  // eigen data per 1-D instance
+
+    constexpr int LDS_OUT   = 4 * PY * PX;  // four DoF planes
+    constexpr int LDS_T     = TY * 2 * 60 * N1; // transpose buffers, two per wave
+    constexpr int LDS_CARRY = TY * WX * NE; // top planes of the previous layer
+    constexpr int LDS_TAB   = 16 * EIG;     // eigen tables / reference matrices
+    constexpr int LDS_TOTAL = LDS_OUT + LDS_T + LDS_CARRY + LDS_TAB;
 
     struct Tiling
     {
@@ -56,20 +70,20 @@ namespace asmamd
       return g.wrap[d] || g.ext_lo[d] < 0; // periodic image or halo cell of the lower rank
     }
 
-    // is tile-relative DoF coordinate Ir (logical I) written by this tile?
+    // is tile-relative DoF coordinate rel (logical I) written by this tile?
     __device__ __forceinline__ bool
-    tile_owns(const DevGrid &g, const int d, const int Ir, const int I)
+    tile_owns(const DevGrid &g, const int d, const int rel, const int I, const int tile_cells)
     {
-      if (I < 0 || I > g.own_hi[d] || Ir < P)
+      if (I < 0 || I > g.own_hi[d] || rel < P)
         return false;
-      return Ir < 4 * TC || I == g.nc[d] * P;
+      return rel < P * tile_cells || I == g.nc[d] * P;
     }
 
+    // FWD: out[a] = sum_i q[i][a] in[i];  else out[i] = sum_a q[i][a] in[a]
     template <bool FWD>
     __device__ __forceinline__ void
     line5(double &u0, double &u1, double &u2, double &u3, double &u4, const double (&q)[NE])
     {
-      // FWD: out[a] = sum_i q[i][a] in[i];  else out[i] = sum_a q[i][a] in[a]
       double o[N1];
 #pragma unroll
       for (int a = 0; a < N1; ++a)
@@ -87,90 +101,171 @@ namespace asmamd
       u3 = o[3];
       u4 = o[4];
     }
-
-    // x and y sweeps on one 5x5 plane v[j*5+i]
+    // sweep along the fast index of v[s*5 + f] / along the slow index
     template <bool FWD>
     __device__ __forceinline__ void
-    plane_x(double (&v)[NE], const double (&q)[NE])
+    sweep_fast(double (&v)[NE], const double (&q)[NE])
     {
 #pragma unroll
-      for (int j = 0; j < N1; ++j)
-        line5<FWD>(v[j * 5 + 0], v[j * 5 + 1], v[j * 5 + 2], v[j * 5 + 3], v[j * 5 + 4], q);
+      for (int s = 0; s < N1; ++s)
+        line5<FWD>(v[s * 5 + 0], v[s * 5 + 1], v[s * 5 + 2], v[s * 5 + 3], v[s * 5 + 4], q);
     }
     template <bool FWD>
     __device__ __forceinline__ void
-    plane_y(double (&v)[NE], const double (&q)[NE])
+    sweep_slow(double (&v)[NE], const double (&q)[NE])
     {
 #pragma unroll
-      for (int i = 0; i < N1; ++i)
-        line5<FWD>(v[0 * 5 + i], v[1 * 5 + i], v[2 * 5 + i], v[3 * 5 + i], v[4 * 5 + i], q);
+      for (int f = 0; f < N1; ++f)
+        line5<FWD>(v[0 * 5 + f], v[1 * 5 + f], v[2 * 5 + f], v[3 * 5 + f], v[4 * 5 + f], q);
     }
 
     __device__ __forceinline__ void
-    load_q(double (&q)[NE], const double *__restrict__ src)
+    load25(double (&q)[NE], const double *__restrict__ src)
     {
 #pragma unroll
       for (int e = 0; e < NE; ++e)
         q[e] = src[e];
     }
 
-    // -------------------------------------------------------------------------
-    // loader / assembler roles: thread (lane, wave) handles tile-relative DoF
-    // column Ir = lane and rows Jr = wave + 4 r (r = 0..16); lanes <= 16 of every
-    // wave additionally handle column Ir = 64, row Jr = wave + 4 lane.
-    // Everything that does not depend on the plane is computed once per kernel.
-    // -------------------------------------------------------------------------
-    constexpr int PITCH = 4 * TC + 2; // LDS pitch of the raw input plane (doubles)
+    // ---------------------------------------------------------------------------
+    // compute role of a lane
+    // ---------------------------------------------------------------------------
+    struct CellLane
+    {
+      int  lane, w, cl, sub; // sub = plane (layout A) or row (layout B) within the cell
+      bool lane_ok;          // lanes 60..63 idle
+      int  cx, cy;
+      bool cell_xy;
+      int      xo[N1], yo[N1]; // storage offsets of the cell's DoF columns / rows
+      unsigned xm, ym;         // existence masks
+      unsigned xd, yd;         // Dirichlet masks
+    };
 
+    __device__ __forceinline__ void
+    cell_lane_setup(const DevGrid &g, const int X0, const int Y0, CellLane &c)
+    {
+      c.lane    = threadIdx.x & 63;
+      c.w       = threadIdx.x >> 6;
+      c.cl      = c.lane / N1;
+      c.sub     = c.lane - c.cl * N1;
+      c.lane_ok = c.lane < WX * N1;
+      c.cx      = X0 + c.cl;
+      c.cy      = Y0 + c.w;
+      c.cell_xy = c.lane_ok && cell_computable(g, 0, c.cx) && cell_computable(g, 1, c.cy);
+      c.xm = c.ym = c.xd = c.yd = 0u;
+#pragma unroll
+      for (int i = 0; i < N1; ++i)
+        {
+          const int  I = P * c.cx + i, J = P * c.cy + i;
+          const bool ex = c.cell_xy && g.exists(0, I), ey = c.cell_xy && g.exists(1, J);
+          c.xo[i] = ex ? (int)(g.store_index(0, I) * g.stride[0]) : 0;
+          c.yo[i] = ey ? (int)(g.store_index(1, J) * g.stride[1]) : 0;
+          c.xm |= (ex ? 1u : 0u) << i;
+          c.ym |= (ey ? 1u : 0u) << i;
+          c.xd |= ((ex && g.dirichlet(0, I)) ? 1u : 0u) << i;
+          c.yd |= ((ey && g.dirichlet(1, J)) ? 1u : 0u) << i;
+        }
+    }
+
+    // gather plane K of the lane's cell; MASK: constrained DoFs read as zero.
+    // Loads are unconditional (offset 0 where nothing exists) so that all 25 are in
+    // flight at once without exec-mask branches.
+    template <bool MASK>
+    __device__ __forceinline__ void
+    gather_plane(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int K, double (&v)[NE])
+    {
+      const bool      zok = c.cell_xy && g.exists(2, K) && !(MASK && g.dirichlet(2, K));
+      const double *  pl  = src + (zok ? g.store_index(2, K) * g.stride[2] : 0);
+      const unsigned  xm = zok ? (MASK ? (c.xm & ~c.xd) : c.xm) : 0u;
+      const unsigned  ym = MASK ? (c.ym & ~c.yd) : c.ym;
+#pragma unroll
+      for (int j = 0; j < N1; ++j)
+#pragma unroll
+        for (int i = 0; i < N1; ++i)
+          {
+            const bool ok = ((xm >> i) & (ym >> j)) & 1u;
+            const double t = pl[ok ? c.yo[j] + c.xo[i] : 0];
+            v[j * 5 + i]   = ok ? t : 0.;
+          }
+    }
+
+    // 5-lane transpose: lane `sub` of a cell holds v[s*5 + f]; afterwards it holds
+    // v'[s*5 + f] = (value v[sub*5 + f] of the cell's lane s).  One fast index f per
+    // round through the wave-private buffer (2 x 300 doubles).
+    __device__ __forceinline__ void
+    transpose5(double (&v)[NE], double *__restrict__ Tw, const CellLane &c)
+    {
+      double n[NE];
+#pragma unroll
+      for (int f = 0; f < N1; ++f)
+        {
+          double *buf = Tw + (f & 1) * (60 * N1);
+          if (c.lane_ok)
+            {
+#pragma unroll
+              for (int s = 0; s < N1; ++s)
+                buf[c.lane * N1 + s] = v[s * 5 + f];
+            }
+          // the partner lanes' stores must be visible: LDS executes a wave's
+          // instructions in order; keep the compiler from moving the loads up
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (c.lane_ok)
+            {
+#pragma unroll
+              for (int s = 0; s < N1; ++s)
+                n[s * 5 + f] = buf[(c.cl * N1 + s) * N1 + c.sub];
+            }
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        v[e] = n[e];
+    }
+
+    // ---------------------------------------------------------------------------
+    // epilogue role: thread (lane, wave) owns tile column Ir = lane (< 49) and rows
+    // Jr = wave + 8 r, r = 0..4, of every output plane
+    // ---------------------------------------------------------------------------
     struct PlaneRole
     {
       int       lane, wave;
-      int       J0, ny, wrap_y, lo_y; // to rebuild the y offset of row r
+      int       J0, ny, wrap_y, lo_y;
       long long stride_y;
-      unsigned  row_exists;    // bit r: row exists in the stored box
-      unsigned  row_owned;     // bit r: row is written by this tile
-      unsigned  row_dirichlet; // bit r: row is a Dirichlet plane
-      long long col_off;       // x part of the offset of column Ir = lane
-      bool      col_exists, col_owned, col_dirichlet;
-      // column 64 element
-      long long x_off;
-      bool      x_exists, x_owned, x_dirichlet;
+      unsigned  row_owned, row_dirichlet;
+      long long col_off;
+      bool      col_in, col_owned, col_dirichlet;
     };
 
     __device__ __forceinline__ void
     role_setup(const DevGrid &g, const int I0, const int J0, PlaneRole &m)
     {
-      m.row_exists = m.row_owned = m.row_dirichlet = 0u;
+      m.lane     = threadIdx.x & 63;
+      m.wave     = threadIdx.x >> 6;
       m.J0       = J0;
       m.ny       = g.nc[1] * g.p;
       m.wrap_y   = g.wrap[1];
       m.lo_y     = g.ext_lo[1];
       m.stride_y = g.stride[1];
+      m.row_owned = m.row_dirichlet = 0u;
 #pragma unroll
       for (int r = 0; r < NR; ++r)
         {
-          const int  Jr = m.wave + 4 * r, J = J0 + Jr;
-          const bool ex = Jr <= 4 * TC && g.exists(1, J);
-          m.row_exists |= (ex ? 1u : 0u) << r;
-          m.row_owned |= ((ex && tile_owns(g, 1, Jr, J)) ? 1u : 0u) << r;
-          m.row_dirichlet |= ((ex && g.dirichlet(1, J)) ? 1u : 0u) << r;
+          const int  Jr = m.wave + TY * r, J = J0 + Jr;
+          const bool ow = Jr < PY && g.exists(1, J) && tile_owns(g, 1, Jr, J, TY);
+          m.row_owned |= (ow ? 1u : 0u) << r;
+          m.row_dirichlet |= ((ow && g.dirichlet(1, J)) ? 1u : 0u) << r;
         }
       const int I     = I0 + m.lane;
-      m.col_exists    = g.exists(0, I);
-      m.col_off       = m.col_exists ? g.store_index(0, I) * g.stride[0] : 0;
-      m.col_owned     = m.col_exists && tile_owns(g, 0, m.lane, I);
-      m.col_dirichlet = m.col_exists && g.dirichlet(0, I);
-      const int Jr = m.wave + 4 * m.lane, J = J0 + Jr, I64 = I0 + 4 * TC;
-      m.x_exists    = m.lane <= TC && Jr <= 4 * TC && g.exists(0, I64) && g.exists(1, J);
-      m.x_off       = m.x_exists ? g.store_index(0, I64) * g.stride[0] + g.store_index(1, J) * g.stride[1] : 0;
-      m.x_owned     = m.x_exists && tile_owns(g, 0, 4 * TC, I64) && tile_owns(g, 1, Jr, J);
-      m.x_dirichlet = m.x_exists && (g.dirichlet(0, I64) || g.dirichlet(1, J));
+      m.col_in        = m.lane < PX;
+      m.col_owned     = m.col_in && g.exists(0, I) && tile_owns(g, 0, m.lane, I, WX);
+      m.col_off       = m.col_owned ? g.store_index(0, I) * g.stride[0] : 0;
+      m.col_dirichlet = m.col_owned && g.dirichlet(0, I);
     }
 
     __device__ __forceinline__ long long
     row_offset(const PlaneRole &m, const int r)
     {
-      int J = m.J0 + m.wave + 4 * r;
+      int J = m.J0 + m.wave + TY * r;
       if (m.wrap_y)
         J += (J < 0) ? m.ny : ((J >= m.ny) ? -m.ny : 0);
       else
@@ -178,395 +273,514 @@ namespace asmamd
       return J * m.stride_y;
     }
 
-    // load plane K of src into registers (zero where nothing exists; MASK additionally
-    // reads constrained DoFs as zero, as read_dof_values does for the operator)
-    template <bool MASK>
-    __device__ __forceinline__ void
-    plane_load(const DevGrid &g, const PlaneRole &m, const double *__restrict__ src, const int K, const bool k_ok,
-               double (&regs)[NR], double &extra)
+    // operands of the fused update for the (up to) 20 DoFs a thread stores per layer;
+    // loaded before the accumulation barriers so that their latency is hidden
+    constexpr int NEP = (N1 - 1) * NR;
+    template <int MODE>
+    struct EpilogueOperands
     {
-      const bool      kz   = k_ok && g.exists(2, K) && !(MASK && g.dirichlet(2, K));
-      const double *  base = src + (kz ? g.store_index(2, K) * g.stride[2] : 0);
-      const bool      cok  = kz && m.col_exists && !(MASK && m.col_dirichlet);
-      const unsigned  rows = cok ? (MASK ? (m.row_exists & ~m.row_dirichlet) : m.row_exists) : 0u;
-      const double *  col  = base + m.col_off;
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        regs[r] = ((rows >> r) & 1u) ? col[row_offset(m, r)] : 0.;
-      extra = (kz && m.x_exists && !(MASK && m.x_dirichlet)) ? base[m.x_off] : 0.;
+      static constexpr bool need_a = (MODE == OP_RESIDUAL || MODE == PC_STEP1 || MODE == PC_UPDATE);
+      static constexpr bool need_b = (MODE == PC_UPDATE);
+      double a[need_a ? NEP : 1];
+      double b[need_b ? NEP : 1];
+    };
+
+    __device__ __forceinline__ long long
+    dof_offset(const DevGrid &g, const PlaneRole &m, const int K, const int r)
+    {
+      return g.store_index(2, K) * g.stride[2] + m.col_off + row_offset(m, r);
     }
 
-    __device__ __forceinline__ void
-    plane_to_lds(const PlaneRole &m, double *__restrict__ S, const double (&regs)[NR], const double extra)
-    {
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        if (m.wave + 4 * r <= 4 * TC)
-          S[(m.wave + 4 * r) * PITCH + m.lane] = regs[r];
-      if (m.lane <= TC && m.wave + 4 * m.lane <= 4 * TC)
-        S[(m.wave + 4 * m.lane) * PITCH + 4 * TC] = extra;
-    }
-
-    // sum of the cells' contributions to one DoF, fixed order
-    __device__ __forceinline__ double
-    stage_out_sum(const double *__restrict__ S, const int Ir, const int Jr)
-    {
-      const int  cxa = Ir >> 2, i = Ir & 3, cya = Jr >> 2, j = Jr & 3;
-      const bool xa = Ir < 4 * TC, xb = (i == 0) && (Ir > 0);
-      const bool ya = Jr < 4 * TC, yb = (j == 0) && (Jr > 0);
-      double     s  = 0.;
-      if (xb && yb)
-        s += S[(4 * 5 + 4) * SP + (cya - 1) * TC + cxa - 1];
-      if (xa && yb)
-        s += S[(4 * 5 + i) * SP + (cya - 1) * TC + cxa];
-      if (xb && ya)
-        s += S[(j * 5 + 4) * SP + cya * TC + cxa - 1];
-      if (xa && ya)
-        s += S[(j * 5 + i) * SP + cya * TC + cxa];
-      return s;
-    }
-
-    // epilogue for one owned DoF: s = (P^-1 src)(dof) or (A src)(dof)
     template <int MODE>
     __device__ __forceinline__ void
-    epilogue_store(const TiledArgs &a, const long long off, const double s, const bool constrained)
+    epilogue_prefetch(const DevGrid &g, const PlaneRole &m, const TiledArgs &a, const int K0, const int nplanes,
+                      EpilogueOperands<MODE> &ops)
     {
-      double t = s;
-      if (MODE == OP_PLAIN || MODE == PC_PLAIN)
-        a.dst[off] = constrained ? 0. : t;
-      else if (MODE == OP_RESIDUAL)
-        // (A x)_c = x_c on constrained DoFs (matrix_free_internal.h:247-255)
-        a.dst[off] = a.b[off] - (constrained ? a.src[off] : t);
-      else
+      if (!EpilogueOperands<MODE>::need_a)
+        return;
+      const double *pa = (MODE == OP_RESIDUAL) ? a.b : a.x;
+#pragma unroll
+      for (int kk = 0; kk < N1 - 1; ++kk)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+          {
+            const bool      own = kk < nplanes && m.col_owned && ((m.row_owned >> r) & 1u);
+            const long long off = own ? dof_offset(g, m, K0 + kk, r) : 0;
+            ops.a[kk * NR + r]  = pa[off];
+            if (EpilogueOperands<MODE>::need_b)
+              ops.b[kk * NR + r] = a.x_old[off];
+          }
+    }
+
+    // store plane kk of S_out as DoF plane K (fused update of the mode) and clear it
+    template <int MODE>
+    __device__ __forceinline__ void
+    plane_epilogue(const DevGrid &g, const PlaneRole &m, const TiledArgs &a, double *__restrict__ S_out, const int kk,
+                   const int K, const EpilogueOperands<MODE> &ops)
+    {
+      if (!m.col_in)
+        return;
+      const bool dk = g.dirichlet(2, K) || m.col_dirichlet;
+      double *   pl = S_out + kk * (PY * PX) + m.lane;
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
         {
-          if (constrained)
-            t = a.src[off];
-          if (MODE == PC_FIRST)
-            a.dst[off] = a.f2 * t;
-          else if (MODE == PC_STEP1)
-            a.dst[off] = a.f1 * a.x[off] + a.f2 * t;
-          else
+          const int Jr = m.wave + TY * r;
+          if (Jr < PY)
             {
-              const double xv = a.x[off];
-              a.dst[off]      = xv + a.f1 * (xv - a.x_old[off]) + a.f2 * t;
+              double t    = pl[Jr * PX];
+              pl[Jr * PX] = 0.;
+              if (m.col_owned && ((m.row_owned >> r) & 1u))
+                {
+                  const long long off         = dof_offset(g, m, K, r);
+                  const bool      constrained = dk || ((m.row_dirichlet >> r) & 1u);
+                  const double    oa = ops.a[EpilogueOperands<MODE>::need_a ? kk * NR + r : 0];
+                  const double    ob = ops.b[EpilogueOperands<MODE>::need_b ? kk * NR + r : 0];
+                  if (MODE == OP_PLAIN || MODE == PC_PLAIN)
+                    a.dst[off] = constrained ? 0. : t;
+                  else if (MODE == OP_RESIDUAL)
+                    // (A x)_c = x_c on constrained DoFs (matrix_free_internal.h:247-255)
+                    a.dst[off] = oa - (constrained ? a.src[off] : t);
+                  else
+                    {
+                      if (constrained)
+                        t = a.src[off]; // unit rows of P^-1 on constrained DoFs
+                      if (MODE == PC_FIRST)
+                        a.dst[off] = a.f2 * t;
+                      else if (MODE == PC_STEP1)
+                        a.dst[off] = a.f1 * oa + a.f2 * t;
+                      else
+                        a.dst[off] = oa + a.f1 * (oa - ob) + a.f2 * t;
+                    }
+                }
             }
         }
     }
 
-    template <int MODE>
+    // add the cell plane o (lane (cell, k), k < 4) into output plane k
     __device__ __forceinline__ void
-    plane_assemble(const DevGrid &g, const PlaneRole &m, const TiledArgs &a, const double *__restrict__ S, const int K)
+    accumulate_plane(double *__restrict__ S_out, const CellLane &c, const int kk, const double (&o)[NE])
     {
-      const long long offk = g.store_index(2, K) * g.stride[2];
-      const bool      dk   = g.dirichlet(2, K);
-      if (m.col_owned)
-        {
-          const long long offx = offk + m.col_off;
-          const bool      dx   = dk || m.col_dirichlet;
-          // rolled on purpose: the unrolled form keeps ~50 loads per thread in flight next to
-          // the 250 registers of the cell tile and spills
-#pragma unroll 4
-          for (int r = 0; r < NR; ++r)
-            if ((m.row_owned >> r) & 1u)
-              epilogue_store<MODE>(a, offx + row_offset(m, r), stage_out_sum(S, m.lane, m.wave + 4 * r),
-                                   dx || ((m.row_dirichlet >> r) & 1u));
-        }
-      if (m.x_owned)
-        epilogue_store<MODE>(a, offk + m.x_off, stage_out_sum(S, 4 * TC, m.wave + 4 * m.lane), dk || m.x_dirichlet);
+      double *pl = S_out + kk * (PY * PX) + (P * c.w) * PX + P * c.cl;
+#pragma unroll
+      for (int j = 0; j < N1; ++j)
+#pragma unroll
+        for (int i = 0; i < N1; ++i)
+          __hip_atomic_fetch_add(pl + j * PX + i, o[j * 5 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
-    // -------------------------------------------------------------------------
-    // FDM sweep
-    // -------------------------------------------------------------------------
-    constexpr int LDS_IN    = (4 * TC + 1) * PITCH; // raw input plane
-    constexpr int LDS_OUT   = NE * SP;              // cell-major output plane
-    constexpr int LDS_CARRY = NE * NT;              // per-cell top plane, private to its lane
-    constexpr int LDS_EIG   = 16 * EIG;             // eigen tables (tensor-product instances)
+    // carry exchange + accumulation of one layer's cell planes
+    template <int MODE>
+    __device__ __forceinline__ void
+    exchange_and_store(const DevGrid &g, const PlaneRole &m, const CellLane &c, const TiledArgs &a, double *__restrict__ S_out,
+                       double *__restrict__ S_carry, double (&o)[NE], const bool active, const bool halo_layer, const int cz)
+    {
+      EpilogueOperands<MODE> ops;
+      if (!halo_layer)
+        epilogue_prefetch<MODE>(g, m, a, P * cz, N1 - 1, ops);
+      double *cw = S_carry + (c.w * WX + c.cl) * NE;
+      // plane 0 receives the top plane of the layer below (same cell column)
+      if (c.lane_ok && c.sub == 0)
+        {
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            o[e] += cw[e];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c.lane_ok && c.sub == N1 - 1)
+        {
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            cw[e] = active ? o[e] : 0.;
+        }
+      if (halo_layer)
+        return; // wave-uniform: the halo layer only feeds the carry
+      // even cell rows, then odd cell rows: rows of equal parity share no DoF row
+      if ((c.w & 1) == 0 && active && c.sub < N1 - 1)
+        accumulate_plane(S_out, c, c.sub, o);
+      __syncthreads();
+      if ((c.w & 1) == 1 && active && c.sub < N1 - 1)
+        accumulate_plane(S_out, c, c.sub, o);
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < N1 - 1; ++kk)
+        plane_epilogue<MODE>(g, m, a, S_out, kk, P * cz + kk, ops);
+      __syncthreads();
+    }
 
+    // top plane of the block (physical boundary): only the last layer contributes
+    template <int MODE>
+    __device__ __forceinline__ void
+    store_top_plane(const DevGrid &g, const PlaneRole &m, const CellLane &c, const TiledArgs &a, double *__restrict__ S_out,
+                    double *__restrict__ S_carry)
+    {
+      EpilogueOperands<MODE> ops;
+      epilogue_prefetch<MODE>(g, m, a, P * g.nc[2], 1, ops);
+      double        o[NE];
+      const double *cw = S_carry + (c.w * WX + c.cl) * NE;
+      const bool    on = c.lane_ok && c.sub == 0;
+      if (on)
+        {
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            o[e] = cw[e];
+        }
+      if ((c.w & 1) == 0 && on)
+        accumulate_plane(S_out, c, 0, o);
+      __syncthreads();
+      if ((c.w & 1) == 1 && on)
+        accumulate_plane(S_out, c, 0, o);
+      __syncthreads();
+      plane_epilogue<MODE>(g, m, a, S_out, 0, P * g.nc[2], ops);
+    }
+
+    __device__ __forceinline__ void
+    lds_clear(double *__restrict__ S_out, double *__restrict__ S_carry)
+    {
+      for (int e = threadIdx.x; e < LDS_OUT; e += NT)
+        S_out[e] = 0.;
+      for (int e = threadIdx.x; e < LDS_CARRY; e += NT)
+        S_carry[e] = 0.;
+    }
+
+    // ---------------------------------------------------------------------------
+    // FDM sweep
+    // ---------------------------------------------------------------------------
     template <int MODE, bool HAS_PRE, bool HAS_POST, bool TENSOR>
-    __global__ void __launch_bounds__(NT, 1)
+    __global__ void __launch_bounds__(NT, 2)
     fdm_tiled_kernel(const DevGrid g, const DevFdm f, const TiledArgs a, const Tiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
-      double *S_in    = lds;
-      double *S_out   = S_in + LDS_IN;
-      double *S_carry = S_out + LDS_OUT;
-      double *S_eig   = S_carry + LDS_CARRY;
+      double *S_out   = lds;
+      double *S_T     = S_out + LDS_OUT;
+      double *S_carry = S_T + LDS_T;
+      double *S_tab   = S_carry + LDS_CARRY;
 
-      const int tid = threadIdx.x;
-      const int b   = blockIdx.x;
+      const int b  = blockIdx.x;
       const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
-      const int X0 = tx * TO - 1, Y0 = ty * TO - 1; // tile cell (0,0)
+      const int X0 = tx * OX - 1, Y0 = ty * OY - 1; // tile cell (0,0)
 
       PlaneRole m;
-      m.lane = tid & 63;
-      m.wave = tid >> 6;
       role_setup(g, P * X0, P * Y0, m);
+      CellLane c;
+      cell_lane_setup(g, X0, Y0, c);
+      double *Tw = S_T + c.w * (2 * 60 * N1);
 
-      // eigen tables of tensor-product meshes live in LDS
-      const bool eig_in_lds = TENSOR && f.n_inst <= 16;
-      if (eig_in_lds)
-        for (int e = tid; e < f.n_inst * EIG; e += NT)
-          S_eig[e] = f.eig[e];
+      // eigen tables of tensor-product meshes live in LDS (the launcher checks n_inst <= 16)
+      if (TENSOR)
+        for (int e = threadIdx.x; e < f.n_inst * EIG; e += NT)
+          S_tab[e] = f.eig[e];
+      lds_clear(S_out, S_carry);
+      __syncthreads();
 
-      // compute role: this lane's cell
-      const int  cxl = tid % TC, cyl = tid / TC;
-      const int  cx = X0 + cxl, cy = Y0 + cyl;
-      const bool cell_xy = cell_computable(g, 0, cx) && cell_computable(g, 1, cy);
-      const int  Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
-      const int  z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
-      const double *in_cell = S_in + (4 * cyl) * PITCH + 4 * cxl;
-
-      double t[N1 * NE]; // the cell tile, index c*25 + b*5 + a
-#pragma unroll
-      for (int e = 0; e < NE; ++e)
-        S_carry[e * NT + tid] = 0.;
-
-      double pre[NR], pre_x; // prefetched plane
-      plane_load<false>(g, m, a.src, P * z_first, true, pre, pre_x);
+      const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
+      const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
 
       for (int cz = z_first; cz < Ze; ++cz)
         {
-          const bool active = cell_xy;
-          int ix = 0, iy = 0, iz = 0;
+          const bool active = c.cell_xy;
+          int        ix = 0, iy = 0, iz = 0;
           if (active)
             {
-              const long long ce = (cx + 1) + (long long)(g.nc[0] + 2) * ((cy + 1) + (long long)(g.nc[1] + 2) * (cz + 1));
-              ix = TENSOR ? f.inst[0][cx + 1] : f.inst[0][ce];
-              iy = TENSOR ? f.inst[1][cy + 1] : f.inst[1][ce];
+              const long long ce =
+                (c.cx + 1) + (long long)(g.nc[0] + 2) * ((c.cy + 1) + (long long)(g.nc[1] + 2) * (cz + 1));
+              ix = TENSOR ? f.inst[0][c.cx + 1] : f.inst[0][ce];
+              iy = TENSOR ? f.inst[1][c.cy + 1] : f.inst[1][ce];
               iz = TENSOR ? f.inst[2][cz + 1] : f.inst[2][ce];
             }
-          if (TENSOR)
-            iz = f.inst[2][cz + 1]; // wave-uniform: the z matrices become scalar operands
-          const double *etab = eig_in_lds ? S_eig : f.eig;
-          const double *ex = etab + ix * EIG, *ey = etab + iy * EIG;
-          const double *ez = (TENSOR ? f.eig : etab) + iz * EIG;
-          double wpx[N1], wpy[N1];
-          if (HAS_PRE)
-            {
-#pragma unroll
-              for (int i = 0; i < N1; ++i)
-                {
-                  wpx[i] = f.w_pre[0][(cx + 1) * N1 + i];
-                  wpy[i] = f.w_pre[1][(cy + 1) * N1 + i];
-                }
-            }
+          // two address spaces, two pointer sets: a merged pointer would compile to flat loads
+          const double *exl = S_tab + ix * EIG, *eyl = S_tab + iy * EIG, *ezl = S_tab + iz * EIG;
+          const double *exg = f.eig + (long long)ix * EIG, *eyg = f.eig + (long long)iy * EIG,
+                       *ezg = f.eig + (long long)iz * EIG;
+#define LOADQ(q, d) \
+  do                \
+    {               \
+      if (TENSOR)   \
+        load25(q, d##l); \
+      else          \
+        load25(q, d##g); \
+    }               \
+  while (0)
 
-          // ---- forward: stream the five src planes of this cell layer ------------
-#pragma unroll 1
-          for (int k = 0; k < N1; ++k)
+          double v[NE], q[NE];
+          // ---- layout A: lane = (cell, z plane k); x and y forward sweeps -----------
+          gather_plane<false>(g, c, a.src, P * cz + c.sub, v);
+          if (active)
             {
-              __syncthreads(); // S_in free
-              plane_to_lds(m, S_in, pre, pre_x);
-              __syncthreads();
-              // prefetch the next plane: k+1 of this layer, or plane 0 of the next layer
-              {
-                const int  Kn   = (k < N1 - 1) ? P * cz + k + 1 : P * (cz + 1);
-                const bool more = (k < N1 - 1) || (cz + 1 < Ze);
-                plane_load<false>(g, m, a.src, Kn, more, pre, pre_x);
-              }
-              if (active)
+              if (HAS_PRE)
                 {
-                  double v[NE];
+                  const double wz = f.w_pre[2][(cz + 1) * N1 + c.sub];
+                  double       wx[N1], wy[N1];
+#pragma unroll
+                  for (int i = 0; i < N1; ++i)
+                    {
+                      wx[i] = f.w_pre[0][(c.cx + 1) * N1 + i];
+                      wy[i] = f.w_pre[1][(c.cy + 1) * N1 + i] * wz;
+                    }
 #pragma unroll
                   for (int j = 0; j < N1; ++j)
 #pragma unroll
                     for (int i = 0; i < N1; ++i)
-                      v[j * 5 + i] = in_cell[j * PITCH + i];
-                  if (HAS_PRE)
-                    {
-                      const double wz = f.w_pre[2][(cz + 1) * N1 + k];
-#pragma unroll
-                      for (int j = 0; j < N1; ++j)
-#pragma unroll
-                        for (int i = 0; i < N1; ++i)
-                          v[j * 5 + i] *= wpx[i] * (wpy[j] * wz);
-                    }
-                  double q[NE];
-                  load_q(q, ex);
-                  plane_x<true>(v, q);
-                  load_q(q, ey);
-                  plane_y<true>(v, q);
-                  // park the x-y transformed plane; the z sweeps run after the fifth plane
-#pragma unroll
-                  for (int kk = 0; kk < N1; ++kk)
-                    if (kk == k)
-                      {
-#pragma unroll
-                        for (int e = 0; e < NE; ++e)
-                          t[kk * NE + e] = v[e];
-                      }
+                      v[j * 5 + i] *= wx[i] * wy[j];
                 }
+              LOADQ(q, ex);
+              sweep_fast<true>(v, q);
+              LOADQ(q, ey);
+              sweep_slow<true>(v, q);
             }
-
-          // ---- z: forward sweep, scale by 1/(lx + ly + lz), backward sweep, line by line ----
+          // ---- layout B: lane = (cell, y index b), v[c*5 + a]; z sweeps + scaling ----
+          transpose5(v, Tw, c);
           if (active)
             {
-              double qz[NE];
-              load_q(qz, ez);
-              const double *inv = f.inv_table != nullptr ?
-                                    f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) :
-                                    nullptr;
-              double lx[N1], ly[N1], lz[N1];
-              if (inv == nullptr)
+              LOADQ(q, ez);
+              sweep_slow<true>(v, q);
+              if (f.inv_table != nullptr)
                 {
+                  const double *inv =
+                    f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) + c.sub * N1;
 #pragma unroll
-                  for (int i = 0; i < N1; ++i)
-                    {
-                      lx[i] = ex[NE + i];
-                      ly[i] = ey[NE + i];
-                      lz[i] = ez[NE + i];
-                    }
-                }
+                  for (int cc = 0; cc < N1; ++cc)
 #pragma unroll
-              for (int e = 0; e < NE; ++e)
-                {
-                  line5<true>(t[0 * NE + e], t[1 * NE + e], t[2 * NE + e], t[3 * NE + e], t[4 * NE + e], qz);
-                  if (inv != nullptr)
-                    {
-#pragma unroll
-                      for (int c = 0; c < N1; ++c)
-                        t[c * NE + e] *= inv[c * NE + e];
-                    }
-                  else
-                    {
-#pragma unroll
-                      for (int c = 0; c < N1; ++c)
-                        {
-                          // reciprocal with two Newton steps (full double precision)
-                          const double sm = lx[e % 5] + (ly[e / 5] + lz[c]);
-                          double       r  = __builtin_amdgcn_rcp(sm);
-                          r               = fma(fma(-sm, r, 1.0), r, r);
-                          r               = fma(fma(-sm, r, 1.0), r, r);
-                          t[c * NE + e] *= r;
-                        }
-                    }
-                  line5<false>(t[0 * NE + e], t[1 * NE + e], t[2 * NE + e], t[3 * NE + e], t[4 * NE + e], qz);
-                }
-            }
-
-          // ---- backward in y, x per output plane; exchange; owners store ----------
-          const bool halo_layer = cz < Zb; // only its top plane (k = 4) is needed
-          double     wqx[N1], wqy[N1];
-          if (HAS_POST)
-            {
-#pragma unroll
-              for (int i = 0; i < N1; ++i)
-                {
-                  wqx[i] = f.w_post[0][(cx + 1) * N1 + i];
-                  wqy[i] = f.w_post[1][(cy + 1) * N1 + i];
-                }
-            }
-#pragma unroll
-          for (int k = 0; k < N1; ++k)
-            {
-              if (halo_layer && k < N1 - 1)
-                continue;
-              double o[NE];
-              if (active)
-                {
-#pragma unroll
-                  for (int e = 0; e < NE; ++e)
-                    o[e] = t[k * NE + e];
-                  double q[NE];
-                  load_q(q, ey);
-                  plane_y<false>(o, q);
-                  load_q(q, ex);
-                  plane_x<false>(o, q);
-                  if (HAS_POST)
-                    {
-                      const double wz = f.w_post[2][(cz + 1) * N1 + k];
-#pragma unroll
-                      for (int j = 0; j < N1; ++j)
-#pragma unroll
-                        for (int i = 0; i < N1; ++i)
-                          o[j * 5 + i] *= wqx[i] * (wqy[j] * wz);
-                    }
+                    for (int aa = 0; aa < N1; ++aa)
+                      v[cc * 5 + aa] *= inv[cc * NE + aa];
                 }
               else
                 {
+                  const double lyb = TENSOR ? eyl[NE + c.sub] : eyg[NE + c.sub];
 #pragma unroll
-                  for (int e = 0; e < NE; ++e)
-                    o[e] = 0.;
+                  for (int cc = 0; cc < N1; ++cc)
+#pragma unroll
+                    for (int aa = 0; aa < N1; ++aa)
+                      {
+                        // reciprocal with two Newton steps (full double precision)
+                        const double sm = (TENSOR ? exl[NE + aa] : exg[NE + aa]) + (lyb + (TENSOR ? ezl[NE + cc] : ezg[NE + cc]));
+                        double       r  = __builtin_amdgcn_rcp(sm);
+                        r               = fma(fma(-sm, r, 1.0), r, r);
+                        r               = fma(fma(-sm, r, 1.0), r, r);
+                        v[cc * 5 + aa] *= r;
+                      }
                 }
-              if (k == N1 - 1)
+              sweep_slow<false>(v, q);
+            }
+          // ---- back to layout A; y and x backward sweeps, post weights ---------------
+          transpose5(v, Tw, c);
+          if (active)
+            {
+              LOADQ(q, ey);
+              sweep_slow<false>(v, q);
+              LOADQ(q, ex);
+              sweep_fast<false>(v, q);
+              if (HAS_POST)
                 {
+                  const double wz = f.w_post[2][(cz + 1) * N1 + c.sub];
+                  double       wx[N1], wy[N1];
 #pragma unroll
-                  for (int e = 0; e < NE; ++e)
-                    S_carry[e * NT + tid] = o[e];
-                  break;
-                }
-              if (k == 0)
-                {
+                  for (int i = 0; i < N1; ++i)
+                    {
+                      wx[i] = f.w_post[0][(c.cx + 1) * N1 + i];
+                      wy[i] = f.w_post[1][(c.cy + 1) * N1 + i] * wz;
+                    }
 #pragma unroll
-                  for (int e = 0; e < NE; ++e)
-                    o[e] += S_carry[e * NT + tid];
+                  for (int j = 0; j < N1; ++j)
+#pragma unroll
+                    for (int i = 0; i < N1; ++i)
+                      v[j * 5 + i] *= wx[i] * wy[j];
                 }
-              __syncthreads(); // S_out free
+            }
+          else
+            {
 #pragma unroll
               for (int e = 0; e < NE; ++e)
-                S_out[e * SP + tid] = o[e];
-              __syncthreads();
-              plane_assemble<MODE>(g, m, a, S_out, P * cz + k);
+                v[e] = 0.;
             }
+          exchange_and_store<MODE>(g, m, c, a, S_out, S_carry, v, active, cz < Zb, cz);
         }
-      // top plane of the block (physical boundary): only the last layer contributes
+#undef LOADQ
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
+        store_top_plane<MODE>(g, m, c, a, S_out, S_carry);
+    }
+
+    // ---------------------------------------------------------------------------
+    // Laplace sweep on Cartesian cells.  For a box cell the sum-factorised
+    // evaluate/integrate pair with exact Gauss quadrature (include/operator.h:866-875)
+    // equals the Kronecker sum  hy hz/hx Mz My Kx + hx hz/hy Mz Ky Mx + hx hy/hz Kz My Mx
+    // of the 1-D reference mass/stiffness matrices, which needs 7 one-dimensional
+    // sweeps instead of 12 and no quadrature-point data.
+    // ---------------------------------------------------------------------------
+    template <int MODE>
+    __global__ void __launch_bounds__(NT, 2)
+    laplace_cart_tiled_kernel(const DevGrid g, const DevOp op, const TiledArgs a, const Tiling tl)
+    {
+      extern __shared__ __attribute__((aligned(16))) double lds[];
+      double *S_out   = lds;
+      double *S_T     = S_out + LDS_OUT;
+      double *S_carry = S_T + LDS_T;
+      double *S_tab   = S_carry + LDS_CARRY;
+
+      const int b  = blockIdx.x;
+      const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
+      const int X0 = tx * OX - 1, Y0 = ty * OY - 1;
+
+      PlaneRole m;
+      role_setup(g, P * X0, P * Y0, m);
+      CellLane c;
+      cell_lane_setup(g, X0, Y0, c);
+      double *Tw = S_T + c.w * (2 * 60 * N1);
+
+      // reference matrices (row-major [i][j], symmetric)
+      if (threadIdx.x < NE)
         {
-          __syncthreads();
-#pragma unroll
-          for (int e = 0; e < NE; ++e)
-            S_out[e * SP + tid] = S_carry[e * NT + tid];
-          __syncthreads();
-          plane_assemble<MODE>(g, m, a, S_out, P * g.nc[2]);
+          S_tab[threadIdx.x]      = op.M_ref[threadIdx.x];
+          S_tab[NE + threadIdx.x] = op.K_ref[threadIdx.x];
         }
+      lds_clear(S_out, S_carry);
+      __syncthreads();
+      const double *Mr = S_tab, *Kr = S_tab + NE;
+
+      const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
+      const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
+      double    hx = 1., hy = 1.;
+      if (c.cell_xy)
+        {
+          hx = op.h[0][c.cx + 1];
+          hy = op.h[1][c.cy + 1];
+        }
+
+      for (int cz = z_first; cz < Ze; ++cz)
+        {
+          const bool   active = c.cell_xy;
+          const double hz     = op.h[2][cz + 1];
+          double       u[NE], t2[NE], q[NE];
+          // ---- layout A: x and y sweeps ------------------------------------------------
+          gather_plane<true>(g, c, a.src, P * cz + c.sub, u);
+          double ca[NE]; // -> needs Mz
+          if (active)
+            {
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                t2[e] = u[e];
+              load25(q, Kr);
+              sweep_fast<true>(t2, q); // t2 = Kx u
+              load25(q, Mr);
+              sweep_fast<true>(u, q); // u  = Mx u  (t1)
+              sweep_slow<true>(t2, q); // My Kx u
+              const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                ca[e] = alpha * t2[e];
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                t2[e] = u[e];
+              sweep_slow<true>(u, q); // My Mx u  -> needs Kz
+              load25(q, Kr);
+              sweep_slow<true>(t2, q); // Ky Mx u
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                {
+                  ca[e] = fma(beta, t2[e], ca[e]);
+                  u[e] *= gamma;
+                }
+            }
+          // ---- layout B: z sweeps ------------------------------------------------------
+          transpose5(ca, Tw, c);
+          transpose5(u, Tw, c);
+          if (active)
+            {
+              load25(q, Kr);
+              sweep_slow<true>(u, q); // Kz (My Mx u)
+              load25(q, Mr);
+              sweep_slow<true>(ca, q); // Mz (...)
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                u[e] += ca[e];
+            }
+          transpose5(u, Tw, c);
+          if (!active)
+            {
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                u[e] = 0.;
+            }
+          exchange_and_store<MODE>(g, m, c, a, S_out, S_carry, u, active, cz < Zb, cz);
+        }
+      if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
+        store_top_plane<MODE>(g, m, c, a, S_out, S_carry);
     }
 
     Tiling
     make_tiling(const DevGrid &g)
     {
       Tiling tl;
-      tl.ntx = (g.nc[0] + TO - 1) / TO;
-      tl.nty = (g.nc[1] + TO - 1) / TO;
+      tl.ntx = (g.nc[0] + OX - 1) / OX;
+      tl.nty = (g.nc[1] + OY - 1) / OY;
       // the last owned plane nc*p of a non-wrapped direction is produced by the tile
       // that holds cell nc-1, no extra tile needed
       const int tiles = tl.ntx * tl.nty;
-      // one workgroup per CU (104 KB of LDS each): aim at ~256 workgroups, chunks of >= 2 layers
-      int best = std::max(1, std::min(256 / tiles, g.nc[2] / 2));
+      // one workgroup per CU: aim at ~2 x 256 workgroups, chunks of >= 4 layers
+      int best = std::max(1, std::min(512 / tiles, g.nc[2] / 4));
       best     = std::min(best, g.nc[2]);
       tl.zlen = (g.nc[2] + best - 1) / best;
       tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
       return tl;
     }
+
+    template <typename K>
+    void
+    set_lds_limit(K kernel)
+    {
+      (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(LDS_TOTAL * sizeof(double)));
+    }
   } // namespace
 
-  bool
-  laplace_tiled(const DevGrid &, const DevOp &, const TiledArgs &, hipStream_t)
+  template <int MODE>
+  static void
+  launch_laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, const Tiling &tl, hipStream_t st)
   {
-    return false;
+    static bool done = false;
+    if (!done)
+      {
+        set_lds_limit(laplace_cart_tiled_kernel<MODE>);
+        done = true;
+      }
+    hipLaunchKernelGGL((laplace_cart_tiled_kernel<MODE>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(NT), LDS_TOTAL * sizeof(double),
+                       st, g, op, a, tl);
+  }
+
+  bool
+  laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st)
+  {
+    if (g.p != P || !op.cartesian)
+      return false;
+    const Tiling tl = make_tiling(g);
+    if (a.mode == OP_PLAIN)
+      launch_laplace_tiled<OP_PLAIN>(g, op, a, tl, st);
+    else if (a.mode == OP_RESIDUAL)
+      launch_laplace_tiled<OP_RESIDUAL>(g, op, a, tl, st);
+    else
+      return false;
+    return true;
   }
 
   template <int MODE, bool HAS_PRE, bool HAS_POST, bool TENSOR>
   static void
   launch_fdm_tiled_t(const DevGrid &g, const DevFdm &f, const TiledArgs &a, const Tiling &tl, hipStream_t st)
   {
-    const size_t lds  = (LDS_IN + LDS_OUT + LDS_CARRY + LDS_EIG) * sizeof(double);
-    static bool  done = false;
+    static bool done = false;
     if (!done)
       {
-        (void)hipFuncSetAttribute((const void *)fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_lds_limit(fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>);
         done = true;
       }
-    hipLaunchKernelGGL((fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(NT), lds, st, g, f, a,
-                       tl);
+    hipLaunchKernelGGL((fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(NT),
+                       LDS_TOTAL * sizeof(double), st, g, f, a, tl);
   }
 
   template <int MODE, bool HAS_PRE, bool HAS_POST>
   static void
   launch_fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, const Tiling &tl, hipStream_t st)
   {
-    if (f.tensor_inst)
+    if (f.tensor_inst && f.n_inst <= 16)
       launch_fdm_tiled_t<MODE, HAS_PRE, HAS_POST, true>(g, f, a, tl, st);
     else
       launch_fdm_tiled_t<MODE, HAS_PRE, HAS_POST, false>(g, f, a, tl, st);
