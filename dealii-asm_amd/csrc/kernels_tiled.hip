@@ -80,9 +80,9 @@ namespace asmamd
     }
 
     // FWD: out[a] = sum_i q[i][a] in[i];  else out[i] = sum_a q[i][a] in[a]
-    template <bool FWD>
+    template <bool FWD, typename Q>
     __device__ __forceinline__ void
-    line5(double &u0, double &u1, double &u2, double &u3, double &u4, const double (&q)[NE])
+    line5(double &u0, double &u1, double &u2, double &u3, double &u4, const Q &q)
     {
       double o[N1];
 #pragma unroll
@@ -102,22 +102,30 @@ namespace asmamd
       u4 = o[4];
     }
     // sweep along the fast index of v[s*5 + f] / along the slow index
-    template <bool FWD>
+    template <bool FWD, typename Q>
     __device__ __forceinline__ void
-    sweep_fast(double (&v)[NE], const double (&q)[NE])
+    sweep_fast(double (&v)[NE], const Q &q)
     {
 #pragma unroll
       for (int s = 0; s < N1; ++s)
         line5<FWD>(v[s * 5 + 0], v[s * 5 + 1], v[s * 5 + 2], v[s * 5 + 3], v[s * 5 + 4], q);
     }
-    template <bool FWD>
+    template <bool FWD, typename Q>
     __device__ __forceinline__ void
-    sweep_slow(double (&v)[NE], const double (&q)[NE])
+    sweep_slow(double (&v)[NE], const Q &q)
     {
 #pragma unroll
       for (int f = 0; f < N1; ++f)
         line5<FWD>(v[0 * 5 + f], v[1 * 5 + f], v[2 * 5 + f], v[3 * 5 + f], v[4 * 5 + f], q);
     }
+
+    // a wave-uniform 5x5 matrix in global memory: the loads become scalar loads and the
+    // entries scalar operands of the FMAs, so they cost no vector registers
+    struct UniformMatrix
+    {
+      const double *__restrict__ p;
+      __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
+    };
 
     __device__ __forceinline__ void
     load25(double (&q)[NE], const double *__restrict__ src)
@@ -492,6 +500,12 @@ namespace asmamd
           const double *exl = S_tab + ix * EIG, *eyl = S_tab + iy * EIG, *ezl = S_tab + iz * EIG;
           const double *exg = f.eig + (long long)ix * EIG, *eyg = f.eig + (long long)iy * EIG,
                        *ezg = f.eig + (long long)iz * EIG;
+          // tensor-product meshes: the y and z matrices depend on the cell row / layer only
+          // (taken from the row / layer index, not from a lane: lane 0 may hold a cell that does not exist)
+          const int iy_u = TENSOR ? f.inst[1][min(max(Y0 + (int)(threadIdx.x >> 6), -1), g.nc[1]) + 1] : 0;
+          const int iz_u = TENSOR ? f.inst[2][cz + 1] : 0;
+          const UniformMatrix Uy{f.eig + (long long)__builtin_amdgcn_readfirstlane(iy_u) * EIG},
+            Uz{f.eig + (long long)__builtin_amdgcn_readfirstlane(iz_u) * EIG};
 #define LOADQ(q, d) \
   do                \
     {               \
@@ -525,15 +539,25 @@ namespace asmamd
                 }
               LOADQ(q, ex);
               sweep_fast<true>(v, q);
-              LOADQ(q, ey);
-              sweep_slow<true>(v, q);
+              if (TENSOR)
+                sweep_slow<true>(v, Uy);
+              else
+                {
+                  LOADQ(q, ey);
+                  sweep_slow<true>(v, q);
+                }
             }
           // ---- layout B: lane = (cell, y index b), v[c*5 + a]; z sweeps + scaling ----
           transpose5(v, Tw, c);
           if (active)
             {
-              LOADQ(q, ez);
-              sweep_slow<true>(v, q);
+              if (TENSOR)
+                sweep_slow<true>(v, Uz);
+              else
+                {
+                  LOADQ(q, ez);
+                  sweep_slow<true>(v, q);
+                }
               if (f.inv_table != nullptr)
                 {
                   const double *inv =
@@ -560,14 +584,22 @@ namespace asmamd
                         v[cc * 5 + aa] *= r;
                       }
                 }
-              sweep_slow<false>(v, q);
+              if (TENSOR)
+                sweep_slow<false>(v, Uz);
+              else
+                sweep_slow<false>(v, q);
             }
           // ---- back to layout A; y and x backward sweeps, post weights ---------------
           transpose5(v, Tw, c);
           if (active)
             {
-              LOADQ(q, ey);
-              sweep_slow<false>(v, q);
+              if (TENSOR)
+                sweep_slow<false>(v, Uy);
+              else
+                {
+                  LOADQ(q, ey);
+                  sweep_slow<false>(v, q);
+                }
               LOADQ(q, ex);
               sweep_fast<false>(v, q);
               if (HAS_POST)
@@ -627,15 +659,11 @@ namespace asmamd
       cell_lane_setup(g, X0, Y0, c);
       double *Tw = S_T + c.w * (2 * 60 * N1);
 
-      // reference matrices (row-major [i][j], symmetric)
-      if (threadIdx.x < NE)
-        {
-          S_tab[threadIdx.x]      = op.M_ref[threadIdx.x];
-          S_tab[NE + threadIdx.x] = op.K_ref[threadIdx.x];
-        }
+      // reference matrices (row-major [i][j], symmetric): wave-uniform scalar operands
+      const UniformMatrix Mm{op.M_ref}, Km{op.K_ref};
+      (void)S_tab;
       lds_clear(S_out, S_carry);
       __syncthreads();
-      const double *Mr = S_tab, *Kr = S_tab + NE;
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
@@ -650,49 +678,47 @@ namespace asmamd
         {
           const bool   active = c.cell_xy;
           const double hz     = op.h[2][cz + 1];
-          double       u[NE], t2[NE], q[NE];
+          double       u[NE], t2[NE];
           // ---- layout A: x and y sweeps ------------------------------------------------
           gather_plane<true>(g, c, a.src, P * cz + c.sub, u);
-          double ca[NE]; // -> needs Mz
           if (active)
             {
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 t2[e] = u[e];
-              load25(q, Kr);
-              sweep_fast<true>(t2, q); // t2 = Kx u
-              load25(q, Mr);
-              sweep_fast<true>(u, q); // u  = Mx u  (t1)
-              sweep_slow<true>(t2, q); // My Kx u
+              sweep_fast<true>(t2, Km); // t2 = Kx u
+              sweep_fast<true>(u, Mm);  // u  = Mx u
               const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
+              // column by column: t2 <- alpha My t2 + beta Ky u  (needs Mz),  u <- gamma My u  (needs Kz)
 #pragma unroll
-              for (int e = 0; e < NE; ++e)
-                ca[e] = alpha * t2[e];
-#pragma unroll
-              for (int e = 0; e < NE; ++e)
-                t2[e] = u[e];
-              sweep_slow<true>(u, q); // My Mx u  -> needs Kz
-              load25(q, Kr);
-              sweep_slow<true>(t2, q); // Ky Mx u
-#pragma unroll
-              for (int e = 0; e < NE; ++e)
+              for (int f = 0; f < N1; ++f)
                 {
-                  ca[e] = fma(beta, t2[e], ca[e]);
-                  u[e] *= gamma;
+                  double k0 = u[0 * 5 + f], k1 = u[1 * 5 + f], k2 = u[2 * 5 + f], k3 = u[3 * 5 + f], k4 = u[4 * 5 + f];
+                  line5<true>(k0, k1, k2, k3, k4, Km); // Ky (Mx u)
+                  line5<true>(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f], Mm);
+                  line5<true>(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f], Mm);
+                  t2[0 * 5 + f] = fma(beta, k0, alpha * t2[0 * 5 + f]);
+                  t2[1 * 5 + f] = fma(beta, k1, alpha * t2[1 * 5 + f]);
+                  t2[2 * 5 + f] = fma(beta, k2, alpha * t2[2 * 5 + f]);
+                  t2[3 * 5 + f] = fma(beta, k3, alpha * t2[3 * 5 + f]);
+                  t2[4 * 5 + f] = fma(beta, k4, alpha * t2[4 * 5 + f]);
+                  u[0 * 5 + f] *= gamma;
+                  u[1 * 5 + f] *= gamma;
+                  u[2 * 5 + f] *= gamma;
+                  u[3 * 5 + f] *= gamma;
+                  u[4 * 5 + f] *= gamma;
                 }
             }
           // ---- layout B: z sweeps ------------------------------------------------------
-          transpose5(ca, Tw, c);
+          transpose5(t2, Tw, c);
           transpose5(u, Tw, c);
           if (active)
             {
-              load25(q, Kr);
-              sweep_slow<true>(u, q); // Kz (My Mx u)
-              load25(q, Mr);
-              sweep_slow<true>(ca, q); // Mz (...)
+              sweep_slow<true>(u, Km);  // Kz (My Mx u)
+              sweep_slow<true>(t2, Mm); // Mz (...)
 #pragma unroll
               for (int e = 0; e < NE; ++e)
-                u[e] += ca[e];
+                u[e] += t2[e];
             }
           transpose5(u, Tw, c);
           if (!active)
