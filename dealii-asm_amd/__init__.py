@@ -70,6 +70,17 @@ class AsmLayout(C.Structure):
     ]
 
 
+class AsmExchangeStep(C.Structure):
+    _fields_ = [
+        ("direction", C.c_int32),
+        ("peer", C.c_int32 * 2),
+        ("send_lo", (C.c_int32 * 3) * 2),
+        ("send_size", (C.c_int32 * 3) * 2),
+        ("recv_lo", (C.c_int32 * 3) * 2),
+        ("recv_size", (C.c_int32 * 3) * 2),
+    ]
+
+
 # every symbol declared in include/dealii_asm_amd.h
 EXPORTED_SYMBOLS = [
     "asm_params_default",
@@ -77,6 +88,7 @@ EXPORTED_SYMBOLS = [
     "asm_destroy",
     "asm_last_error",
     "asm_describe_layout",
+    "asm_exchange_plan",
     "asm_comm_unique_id",
     "asm_comm_init",
     "asm_vector_layout",
@@ -125,6 +137,7 @@ def load_library():
     lib.asm_destroy.argtypes = [C.c_void_p]
     lib.asm_destroy.restype = None
     lib.asm_describe_layout.argtypes = [C.POINTER(AsmParams), C.POINTER(AsmLayout)]
+    lib.asm_exchange_plan.argtypes = [C.POINTER(AsmParams), C.c_int, C.POINTER(AsmExchangeStep), C.POINTER(C.c_int32)]
     lib.asm_vector_layout.argtypes = [C.c_void_p, C.POINTER(AsmLayout)]
     lib.asm_vector_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.asm_vector_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -220,6 +233,17 @@ def describe_layout(params: AsmParams) -> AsmLayout:
     if err:
         raise ValueError(lib.asm_last_error(None).decode())
     return out
+
+
+def exchange_plan(params: AsmParams, add: bool):
+    """list of asm_exchange_step of update_ghost_values (add=False) / compress(add)"""
+    lib = load_library()
+    steps = (AsmExchangeStep * 3)()
+    n = C.c_int32()
+    err = lib.asm_exchange_plan(C.byref(params), 1 if add else 0, steps, C.byref(n))
+    if err:
+        raise ValueError(lib.asm_last_error(None).decode())
+    return [steps[i] for i in range(n.value)]
 
 
 class DeviceVector:

@@ -145,65 +145,24 @@ namespace
         ctx->error = "world_size > 1 but asm_comm_init() has not been called";
         return ASM_ERR_INVALID_VALUE;
       }
-    const DevGrid &g = ctx->g;
-    // ghost plane counts below plane 0 / from plane nc*p upwards; the same on every rank
-    const int n_lo = ctx->s.halo_lo, n_hi = ctx->s.halo_hi;
-    for (int step = 0; step < 3; ++step)
+    const DevGrid &   g = ctx->g;
+    asm_exchange_step steps[3];
+    const int         n_steps = build_exchange_plan(ctx->s, add, steps);
+    for (int i = 0; i < n_steps; ++i)
       {
-        const int d  = add ? 2 - step : step;
-        const int np = g.nc[d] * g.p;
-        if (g.wrap[d])
-          continue;
-        const bool lo_if = ctx->s.face[d][0] == FACE_INTERFACE, hi_if = ctx->s.face[d][1] == FACE_INTERFACE;
-        // tangential extents: lower directions carry their ghost planes (update: they
-        // were filled before; add: they are forwarded afterwards), higher ones do not
-        int lo[3], size[3];
-        for (int e = 0; e < 3; ++e)
-          {
-            if (g.wrap[e])
-              {
-                lo[e]   = 0;
-                size[e] = g.nc[e] * g.p;
-              }
-            else if (e < d)
-              {
-                lo[e]   = g.ext_lo[e];
-                size[e] = g.ext_hi[e] - g.ext_lo[e] + 1;
-              }
-            else
-              {
-                lo[e]   = 0;
-                size[e] = g.own_hi[e] + 1;
-              }
-          }
-        const long long plane = (long long)(d == 0 ? 1 : size[0]) * (d == 1 ? 1 : size[1]) * (d == 2 ? 1 : size[2]);
-        // [0]: exchanged with the LOW neighbour, [1]: with the HIGH neighbour
-        // owned planes the neighbours ghost:   low neighbour: [0, n_hi)   high neighbour: [np - n_lo, np)
-        // my ghost planes:                     low: [-n_lo, 0)            high: [np, np + n_hi)
-        int own_lo[2] = {0, np - n_lo}, own_n[2] = {lo_if ? n_hi : 0, hi_if ? n_lo : 0};
-        int gh_lo[2] = {-n_lo, np}, gh_n[2] = {lo_if ? n_lo : 0, hi_if ? n_hi : 0};
-        int send_lo[2][3], send_size[2][3], recv_lo[2][3], recv_size[2][3];
-        long long cnt_send[2], cnt_recv[2];
+        const asm_exchange_step &st = steps[i];
+        long long                cnt_send[2], cnt_recv[2];
         for (int sd = 0; sd < 2; ++sd)
           {
-            for (int e = 0; e < 3; ++e)
-              {
-                send_lo[sd][e] = recv_lo[sd][e] = lo[e];
-                send_size[sd][e] = recv_size[sd][e] = size[e];
-              }
-            send_lo[sd][d]   = add ? gh_lo[sd] : own_lo[sd];
-            send_size[sd][d] = add ? gh_n[sd] : own_n[sd];
-            recv_lo[sd][d]   = add ? own_lo[sd] : gh_lo[sd];
-            recv_size[sd][d] = add ? own_n[sd] : gh_n[sd];
-            cnt_send[sd]     = plane * send_size[sd][d];
-            cnt_recv[sd]     = plane * recv_size[sd][d];
+            cnt_send[sd] = st.peer[sd] < 0 ? 0 : (long long)st.send_size[sd][0] * st.send_size[sd][1] * st.send_size[sd][2];
+            cnt_recv[sd] = st.peer[sd] < 0 ? 0 : (long long)st.recv_size[sd][0] * st.recv_size[sd][1] * st.recv_size[sd][2];
             if (cnt_send[sd] > ctx->hbuf_size || cnt_recv[sd] > ctx->hbuf_size)
               {
                 ctx->error = "internal error: halo buffer too small";
                 return ASM_ERR_INVALID_VALUE;
               }
             if (cnt_send[sd] > 0)
-              vec_box(g, 0, v, ctx->hbuf[sd], send_lo[sd], send_size[sd], ctx->stream);
+              vec_box(g, 0, v, ctx->hbuf[sd], st.send_lo[sd], st.send_size[sd], ctx->stream);
           }
         NCCL_TRY(ncclGroupStart());
         // sends: low then high; receives: high then low, so that with two ranks in a
@@ -211,18 +170,18 @@ namespace
         // side meets the k-th receive of the other
         for (int sd = 0; sd < 2; ++sd)
           if (cnt_send[sd] > 0)
-            NCCL_TRY(ncclSend(ctx->hbuf[sd], cnt_send[sd], ncclDouble, ctx->s.nbr[d][sd], ctx->comm, ctx->stream));
+            NCCL_TRY(ncclSend(ctx->hbuf[sd], cnt_send[sd], ncclDouble, st.peer[sd], ctx->comm, ctx->stream));
         for (int sd = 1; sd >= 0; --sd)
           if (cnt_recv[sd] > 0)
-            NCCL_TRY(ncclRecv(ctx->hbuf[2 + sd], cnt_recv[sd], ncclDouble, ctx->s.nbr[d][sd], ctx->comm, ctx->stream));
+            NCCL_TRY(ncclRecv(ctx->hbuf[2 + sd], cnt_recv[sd], ncclDouble, st.peer[sd], ctx->comm, ctx->stream));
         NCCL_TRY(ncclGroupEnd());
         for (int sd = 0; sd < 2; ++sd)
           if (cnt_recv[sd] > 0)
-            vec_box(g, add ? 2 : 1, v, ctx->hbuf[2 + sd], recv_lo[sd], recv_size[sd], ctx->stream);
+            vec_box(g, add ? 2 : 1, v, ctx->hbuf[2 + sd], st.recv_lo[sd], st.recv_size[sd], ctx->stream);
         if (add) // zero_out_ghost_values
           for (int sd = 0; sd < 2; ++sd)
             if (cnt_send[sd] > 0)
-              vec_box(g, 3, v, nullptr, send_lo[sd], send_size[sd], ctx->stream);
+              vec_box(g, 3, v, nullptr, st.send_lo[sd], st.send_size[sd], ctx->stream);
       }
     return ASM_OK;
   }
@@ -499,6 +458,19 @@ asm_describe_layout(const asm_params *p, asm_layout *out)
       return ASM_ERR_INVALID_VALUE;
     }
   fill_layout(s, out);
+  return ASM_OK;
+}
+
+int
+asm_exchange_plan(const asm_params *p, int add, asm_exchange_step steps[3], int32_t *n_steps)
+{
+  HostSetup s;
+  if (!setup_layout(*p, s))
+    {
+      g_create_error = s.error;
+      return ASM_ERR_INVALID_VALUE;
+    }
+  *n_steps = build_exchange_plan(s, add != 0, steps);
   return ASM_OK;
 }
 

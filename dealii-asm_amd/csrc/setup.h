@@ -325,6 +325,73 @@ namespace asmamd
   }
 
   // ---------------------------------------------------------------------
+  // ghost exchange plan: dimension-by-dimension slabs (x, then y with the x ghosts,
+  // then z), the structured-block equivalent of Partitioner::export_to_ghosted_array
+  // (include/matrix_free_internal.h:13-47); add = true is the reverse
+  // (import_from_ghosted_array with VectorOperation::add, :49-84) in the order z, y, x.
+  // Boxes are in local logical DoF coordinates; index [0] = low neighbour, [1] = high.
+  // ---------------------------------------------------------------------
+  inline int
+  build_exchange_plan(const HostSetup &s, const bool add, asm_exchange_step steps[3])
+  {
+    const DevGrid &g   = s.g;
+    const int      n_lo = s.halo_lo, n_hi = s.halo_hi;
+    int            n_steps = 0;
+    for (int step = 0; step < 3; ++step)
+      {
+        const int d  = add ? 2 - step : step;
+        const int np = g.nc[d] * g.p;
+        if (g.wrap[d])
+          continue;
+        const bool lo_if = s.face[d][0] == FACE_INTERFACE, hi_if = s.face[d][1] == FACE_INTERFACE;
+        if (!lo_if && !hi_if)
+          continue;
+        asm_exchange_step &st = steps[n_steps++];
+        st.direction          = d;
+        st.peer[0]            = lo_if ? s.nbr[d][0] : -1;
+        st.peer[1]            = hi_if ? s.nbr[d][1] : -1;
+        // tangential extents: lower directions carry their ghost planes (update: they were
+        // filled before; add: they are forwarded afterwards), higher ones do not
+        int lo[3], size[3];
+        for (int e = 0; e < 3; ++e)
+          {
+            if (g.wrap[e])
+              {
+                lo[e]   = 0;
+                size[e] = g.nc[e] * g.p;
+              }
+            else if (e < d)
+              {
+                lo[e]   = g.ext_lo[e];
+                size[e] = g.ext_hi[e] - g.ext_lo[e] + 1;
+              }
+            else
+              {
+                lo[e]   = 0;
+                size[e] = g.own_hi[e] + 1;
+              }
+          }
+        // owned planes the neighbours ghost:   low neighbour: [0, n_hi)   high neighbour: [np - n_lo, np)
+        // my ghost planes:                     low: [-n_lo, 0)            high: [np, np + n_hi)
+        const int own_lo[2] = {0, np - n_lo}, own_n[2] = {lo_if ? n_hi : 0, hi_if ? n_lo : 0};
+        const int gh_lo[2] = {-n_lo, np}, gh_n[2] = {lo_if ? n_lo : 0, hi_if ? n_hi : 0};
+        for (int sd = 0; sd < 2; ++sd)
+          {
+            for (int e = 0; e < 3; ++e)
+              {
+                st.send_lo[sd][e] = st.recv_lo[sd][e] = lo[e];
+                st.send_size[sd][e] = st.recv_size[sd][e] = size[e];
+              }
+            st.send_lo[sd][d]   = add ? gh_lo[sd] : own_lo[sd];
+            st.send_size[sd][d] = add ? gh_n[sd] : own_n[sd];
+            st.recv_lo[sd][d]   = add ? own_lo[sd] : gh_lo[sd];
+            st.recv_size[sd][d] = add ? own_n[sd] : gh_n[sd];
+          }
+      }
+    return n_steps;
+  }
+
+  // ---------------------------------------------------------------------
   // geometry
   // ---------------------------------------------------------------------
   struct Geometry

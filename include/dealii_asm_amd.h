@@ -149,6 +149,19 @@ typedef struct asm_layout
   int32_t proc_coord[3];
 } asm_layout;
 
+/* one direction of the ghost exchange: boxes in LOCAL logical DoF coordinates
+ * (subtract asm_layout::store_begin for storage indices); index [0] is the low
+ * neighbour, [1] the high neighbour; peer < 0 or size 0 = nothing to do.
+ * Both sides post their sends in the order low, high and their receives in the
+ * order high, low. */
+typedef struct asm_exchange_step
+{
+  int32_t direction;
+  int32_t peer[2];
+  int32_t send_lo[2][3], send_size[2][3];
+  int32_t recv_lo[2][3], recv_size[2][3];
+} asm_exchange_step;
+
 /* ----- life cycle ------------------------------------------------------- */
 
 /* fills *p with the reference's defaults */
@@ -164,6 +177,12 @@ const char *asm_last_error(const asm_ctx *ctx); /* ctx may be NULL: last creatio
 /* host-only description of what rank `rank` would own; needs no GPU
  * (used by the multi-process CPU tests) */
 int asm_describe_layout(const asm_params *p, asm_layout *out);
+
+/* host-only: the (up to 3) steps of update_ghost_values (add = 0) or of
+ * compress(add) (add = 1, received values are ADDED, sent ghost planes zeroed
+ * afterwards) that rank `p->rank` executes; this is the plan asm_update_ghost_values
+ * / asm_compress_add run over RCCL.  Needs no GPU. */
+int asm_exchange_plan(const asm_params *p, int add, asm_exchange_step steps[3], int32_t *n_steps);
 
 /* RCCL bootstrap: rank 0 fills a 128-byte id, the host broadcasts it, every rank
  * joins.  Replaces the MPI communicator held by deal.II's Partitioner. */

@@ -1,0 +1,99 @@
+"""CPU-side checks of the C ABI: the in-tree library loads, exports every symbol the
+header declares, describes layouts / exchange plans without a GPU, and refuses to
+run (instead of falling back to the CPU) when no HIP device is present."""
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported(pkg):
+    header = open(os.path.join(ROOT, "include", "dealii_asm_amd.h")).read()
+    declared = set(re.findall(r"\b(asm_[a-z_0-9]+)\s*\(", header))
+    lib = pkg.load_library()
+    assert declared == set(pkg.EXPORTED_SYMBOLS), declared ^ set(pkg.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_header_cites_reference_interfaces():
+    header = open(os.path.join(ROOT, "include", "dealii_asm_amd.h")).read()
+    for cite in ("include/operator.h:1353-1365", "include/matrix_free.h:925-954", "include/matrix_free_internal.h"):
+        assert cite in header
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("boundary", ["dirichlet", "periodic"])
+@pytest.mark.parametrize("kernel", ["generic", "tiled"])
+def test_layout_partitions_all_dofs(pkg, world, boundary, kernel):
+    nc, p = (8, 12, 16), 4
+    n_glob = 1
+    for d in range(3):
+        n_glob *= nc[d] * p + (0 if boundary == "periodic" else 1)
+    owned = np.zeros([nc[d] * p + 1 for d in range(3)], dtype=int)
+    total = 0
+    for rank in range(world):
+        prm = pkg.make_params(degree=p, n_cells=nc, boundary=boundary, world_size=world, rank=rank, kernel=kernel)
+        L = pkg.describe_layout(prm)
+        assert L.n_global_dofs == n_glob
+        sl = tuple(slice(L.owned_begin[d], L.owned_begin[d] + L.owned_size[d]) for d in range(3))
+        owned[sl] += 1
+        total += L.n_owned
+        assert L.n_alloc >= L.n_owned + L.n_ghost
+        assert L.stride[1] % 8 == 0  # padded rows: 64-byte aligned row starts
+        assert all(L.store_begin[d] <= 0 for d in range(3))
+        assert np.prod([L.proc_grid[d] for d in range(3)]) == world
+    assert total == n_glob
+    glob = tuple(slice(0, nc[d] * p + (0 if boundary == "periodic" else 1)) for d in range(3))
+    assert np.all(owned[glob] == 1)
+
+
+def test_exchange_plans_are_consistent(pkg):
+    """what one rank sends is what its peer expects to receive, for every patch type"""
+    cases = [dict(n_overlap=1, kernel="generic"), dict(n_overlap=2, kernel="generic"), dict(element_centric=False, kernel="generic"),
+             dict(n_overlap=1, kernel="tiled")]
+    for kw, world, boundary in itertools.product(cases, [2, 8], ["dirichlet", "periodic"]):
+        plans = {}
+        for add in (False, True):
+            for rank in range(world):
+                prm = pkg.make_params(degree=4, n_cells=(8, 8, 8), boundary=boundary, world_size=world, rank=rank, **kw)
+                plans[(add, rank)] = pkg.exchange_plan(prm, add)
+        for (add, rank), steps in plans.items():
+            for st in steps:
+                for side in (0, 1):
+                    peer = st.peer[side]
+                    n_send = int(np.prod(list(st.send_size[side]))) if peer >= 0 else 0
+                    if n_send == 0:
+                        continue
+                    other = [s for s in plans[(add, peer)] if s.direction == st.direction][0]
+                    # my low neighbour receives it from its high side and vice versa
+                    assert other.peer[1 - side] == rank
+                    assert list(other.recv_size[1 - side]) == list(st.send_size[side])
+
+
+def test_invalid_parameters_are_reported(pkg):
+    bad = pkg.make_params(degree=9)
+    with pytest.raises(ValueError, match="degree"):
+        pkg.describe_layout(bad)
+    bad = pkg.make_params(boundary=[("periodic", "dirichlet")] * 3)
+    with pytest.raises(ValueError, match="periodic"):
+        pkg.describe_layout(bad)
+    bad = pkg.make_params(degree=3, kernel="tiled")
+    with pytest.raises(ValueError, match="tiled"):
+        pkg.describe_layout(bad)
+
+
+def test_no_cpu_fallback(pkg):
+    import ctypes
+
+    lib = pkg.load_library()
+    n = ctypes.c_int(0)
+    hip = ctypes.CDLL("libamdhip64.so")
+    if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pkg.Context(n_cells=(2, 2, 2))

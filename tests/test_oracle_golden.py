@@ -1,0 +1,136 @@
+"""Pins the oracle (oracle/asm_oracle.py) against everything the reference's own
+tests hold for the hot path:
+  1. the eigenvalue estimates printed in tests/element_centered_preconitioners/small/*.output,
+  2. the fdm_01.cc invariant (FDM inverse == dense inverse of the restricted block),
+  3. the cross-fixture invariant "full-overlap FDM == exact additive Schwarz",
+  4. subdivided_hyper_cube_balanced_01.output (benchmark mesh sizes)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import asm_oracle as orc
+from dealii_numbering import dealii_numbering_2d
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_small_outputs.json")))
+
+
+def power_iteration_estimate(level, fixture):
+    nc = 2**level
+    mesh = orc.Mesh((nc, nc), 3, [orc.DIRICHLET, orc.DIRICHLET])
+    op = orc.LaplaceOperator(mesh)
+    if fixture.get("precond") == "Diagonal":
+        prec = orc.JacobiPreconditioner(op)
+    else:
+        prec = orc.ASPoissonPreconditioner(mesh, fixture["n_overlap"], fixture["weighting"])
+    if level == 0:
+        num = np.arange(mesh.n_dofs)
+    else:
+        num = dealii_numbering_2d(level, 3)
+    v = (num % 11).astype(float)
+    v -= v.mean()
+    v[op.constrained] = 0.0
+    # the fixtures were produced with 20 power iterations (the constant is 40 in the
+    # checked-in source, precondition.templates.h:111; 20 reproduces all 21 numbers)
+    return orc.power_iteration(op, prec, v, 20)
+
+
+@pytest.mark.parametrize("fixture", GOLD["fixtures"], ids=lambda f: f["file"])
+def test_reference_eigenvalue_estimates(fixture):
+    """6 significant digits, as printed by the reference"""
+    for level, gold in enumerate(fixture["min_ev"]):
+        if gold is None:
+            continue
+        est = power_iteration_estimate(level, fixture)
+        assert float(f"{est:.6g}") == pytest.approx(gold, abs=1.01e-5 * max(1.0, gold)), (level, est, gold)
+
+
+def test_mesh_size_table():
+    for s, row in GOLD["mesh_sizes"].items():
+        if s.startswith("_"):
+            continue
+        n_refine, sub = orc.decompose_for_subdivided_hyper_cube_balanced(3, int(s))
+        assert [n_refine] + sub == row
+
+
+def _restricted_block_inverse(A, idx, valid):
+    ii = idx[valid]
+    return ii, np.linalg.inv(A[np.ix_(ii, ii)])
+
+
+@pytest.mark.parametrize("dim,p,n_overlap", [(2, 2, 1), (2, 3, 2), (2, 3, 3), (3, 2, 1), (3, 2, 2)])
+def test_fdm_equals_dense_block_inverse(dim, p, n_overlap):
+    """fdm_01.cc:148-177 on a non-uniform Cartesian mesh with Dirichlet boundaries"""
+    nc = (4, 3, 3)[:dim]
+    h = [1.1 ** np.arange(n) / (1.1 ** np.arange(n)).sum() for n in nc]
+    mesh = orc.Mesh(nc, p, [orc.DIRICHLET] * dim, h=h)
+    A = orc.LaplaceOperator(mesh).dense()
+    P = orc.ASPoissonPreconditioner(mesh, n_overlap, "none")
+    rng = np.random.default_rng(1)
+    for c in rng.choice(mesh.ncells, size=min(6, mesh.ncells), replace=False):
+        valid = P.valid[c].reshape(-1)
+        ii, Binv = _restricted_block_inverse(A, P.idx[c].reshape(-1), valid)
+        rhs = rng.standard_normal(len(ii))
+        T = np.zeros((mesh.ncells,) + P.idx.shape[1:])
+        T[c].reshape(-1)[valid] = rhs
+        out = P.apply_inverse(T)[c].reshape(-1)
+        assert np.allclose(out[valid], Binv @ rhs, rtol=1e-10, atol=1e-12)
+        assert np.all(out[~valid] == 0.0)
+
+
+@pytest.mark.parametrize("weighting", ["none", "post", "symm"])
+def test_full_overlap_fdm_equals_exact_asm(weighting):
+    """dummy_mg_chebyshev_fdm_3.output == dummy_mg_chebyshev_asm.output"""
+    mesh = orc.Mesh((4, 4), 3, [orc.DIRICHLET, orc.DIRICHLET])
+    A = orc.LaplaceOperator(mesh).dense()
+    P = orc.ASPoissonPreconditioner(mesh, 3, weighting)
+    n = mesh.n_dofs
+    exact = np.zeros((n, n))
+    for c in range(mesh.ncells):
+        valid = P.valid[c].reshape(-1)
+        ii, Binv = _restricted_block_inverse(A, P.idx[c].reshape(-1), valid)
+        wpre = np.ones(len(ii)) if P.w_pre is None else P.w_pre[c].reshape(-1)[valid]
+        wpost = np.ones(len(ii)) if P.w_post is None else P.w_post[c].reshape(-1)[valid]
+        exact[np.ix_(ii, ii)] += wpost[:, None] * Binv * wpre[None, :]
+    assert np.allclose(P.dense(), exact, rtol=1e-10, atol=1e-12)
+
+
+def test_operator_energy_and_symmetry():
+    """u^T A u = int |grad u|^2 for u = x^2 + y z on a Cartesian mesh (exact quadrature)"""
+    mesh = orc.Mesh((3, 2, 2), 3, [orc.NEUMANN] * 3)
+    op = orc.LaplaceOperator(mesh)
+    b = mesh.basis
+    xs = [np.concatenate([(c + b.nodes[:-1]) / n for c in range(n)] + [[1.0]]) for n in mesh.nc]
+    X, Y, Z = np.meshgrid(xs[0], xs[1], xs[2], indexing="ij")
+    u = (X**2 + Y * Z).transpose(2, 1, 0).reshape(-1)
+    # int (2x)^2 + z^2 + y^2 = 4/3 + 1/3 + 1/3
+    assert u @ op.vmult(u) == pytest.approx(2.0, rel=1e-12)
+    assert np.abs(op.vmult(np.ones(mesh.n_dofs))).max() < 1e-12
+
+
+def test_kershaw_map_properties():
+    pts = np.random.default_rng(0).uniform(0, 1, (200, 3))
+    assert np.allclose(orc.kershaw(1.0, 1.0, pts), pts)  # eps = 1: identity (kershaw.h:38)
+    out = orc.kershaw(0.3, 0.3, pts)
+    assert np.all((out >= -1e-15) & (out <= 1 + 1e-15))
+    corners = np.array([[0, 0, 0], [1, 1, 1], [0.5, 0, 1]], float)
+    assert np.allclose(orc.kershaw(0.3, 0.3, corners), corners)
+
+
+def test_chebyshev_vmult_is_step_from_zero():
+    mesh = orc.Mesh((3, 3), 3, [orc.DIRICHLET, orc.PERIODIC])
+    op = orc.LaplaceOperator(mesh)
+    prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
+    b = np.random.default_rng(3).standard_normal(mesh.n_dofs)
+    for degree in (1, 2, 4):
+        cheb = orc.Chebyshev(op, prec, degree=degree)
+        assert np.allclose(cheb.vmult(b), cheb.step(np.zeros_like(b), b), rtol=1e-13, atol=1e-14)
+    # the smoother damps the residual of the preconditioned system
+    cheb = orc.Chebyshev(op, prec, degree=3)
+    x = cheb.vmult(b)
+    r0 = b.copy()
+    r0[op.constrained] = 0
+    r1 = b - op.vmult(x, unit_constrained=True)
+    assert np.linalg.norm(r1) < np.linalg.norm(r0)
