@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdealii_asm_amd.so")
+LIB_PATH = os.environ.get("DEALII_ASM_AMD_LIB", os.path.join(_HERE, "libdealii_asm_amd.so"))
 
 BC = {"periodic": 0, "dirichlet": 1, "neumann": 2}
 WEIGHTING = {"none": 0, "pre": 1, "post": 2, "ras": 3, "symm": 4}

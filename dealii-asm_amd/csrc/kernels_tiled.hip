@@ -84,6 +84,9 @@ namespace asmamd
     __device__ __forceinline__ void
     line5(double &u0, double &u1, double &u2, double &u3, double &u4, const Q &q)
     {
+#if defined(ASM_ABLATE) && (ASM_ABLATE == 1 || ASM_ABLATE >= 4)
+      return; // diagnostic build: sweeps removed (results are wrong)
+#endif
       double o[N1];
 #pragma unroll
       for (int a = 0; a < N1; ++a)
@@ -176,25 +179,37 @@ namespace asmamd
     }
 
     // gather plane K of the lane's cell; MASK: constrained DoFs read as zero.
-    // Loads are unconditional (offset 0 where nothing exists) so that all 25 are in
-    // flight at once without exec-mask branches.
+    // Every DoF of a computable cell exists (the patch is the cell itself), so the 25
+    // loads need no predicate; lanes without a cell read offset 0 and are zeroed by the
+    // caller.  Dirichlet masking only touches lanes whose cell lies on the boundary.
     template <bool MASK>
     __device__ __forceinline__ void
     gather_plane(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int K, double (&v)[NE])
     {
-      const bool      zok = c.cell_xy && g.exists(2, K) && !(MASK && g.dirichlet(2, K));
-      const double *  pl  = src + (zok ? g.store_index(2, K) * g.stride[2] : 0);
-      const unsigned  xm = zok ? (MASK ? (c.xm & ~c.xd) : c.xm) : 0u;
-      const unsigned  ym = MASK ? (c.ym & ~c.yd) : c.ym;
+      const double *pl = src + (c.cell_xy ? g.store_index(2, K) * g.stride[2] : 0);
+#if defined(ASM_ABLATE) && ASM_ABLATE == 4
+      for (int e = 0; e < NE; ++e)
+        v[e] = 1.0 + e + K; // diagnostic build: no gather
+      return;
+#endif
 #pragma unroll
       for (int j = 0; j < N1; ++j)
 #pragma unroll
         for (int i = 0; i < N1; ++i)
-          {
-            const bool ok = ((xm >> i) & (ym >> j)) & 1u;
-            const double t = pl[ok ? c.yo[j] + c.xo[i] : 0];
-            v[j * 5 + i]   = ok ? t : 0.;
-          }
+          v[j * 5 + i] = pl[c.yo[j] + c.xo[i]];
+      if (MASK)
+        {
+          const bool zd = g.dirichlet(2, K);
+          if (c.cell_xy && (zd || (c.xd | c.yd) != 0u))
+            {
+#pragma unroll
+              for (int j = 0; j < N1; ++j)
+#pragma unroll
+                for (int i = 0; i < N1; ++i)
+                  if (zd || (((c.xd >> i) | (c.yd >> j)) & 1u))
+                    v[j * 5 + i] = 0.;
+            }
+        }
     }
 
     // 5-lane transpose: lane `sub` of a cell holds v[s*5 + f]; afterwards it holds
@@ -203,6 +218,9 @@ namespace asmamd
     __device__ __forceinline__ void
     transpose5(double (&v)[NE], double *__restrict__ Tw, const CellLane &c)
     {
+#if defined(ASM_ABLATE) && (ASM_ABLATE == 3 || ASM_ABLATE == 1 || ASM_ABLATE >= 4)
+      return; // diagnostic build: transposes removed (results are wrong)
+#endif
       double n[NE];
 #pragma unroll
       for (int f = 0; f < N1; ++f)
@@ -306,6 +324,11 @@ namespace asmamd
     {
       if (!EpilogueOperands<MODE>::need_a)
         return;
+#if defined(ASM_ABLATE) && (ASM_ABLATE == 6 || ASM_ABLATE == 7)
+      for (int e = 0; e < NEP; ++e)
+        ops.a[e] = 1.0 + e; // diagnostic build: no operand loads
+      return;
+#endif
       const double *pa = (MODE == OP_RESIDUAL) ? a.b : a.x;
 #pragma unroll
       for (int kk = 0; kk < N1 - 1; ++kk)
@@ -338,6 +361,10 @@ namespace asmamd
             {
               double t    = pl[Jr * PX];
               pl[Jr * PX] = 0.;
+#if defined(ASM_ABLATE) && ASM_ABLATE == 6
+              if (t != 1.2345e300)
+                continue; // diagnostic build: no stores
+#endif
               if (m.col_owned && ((m.row_owned >> r) & 1u))
                 {
                   const long long off         = dof_offset(g, m, K, r);
@@ -370,6 +397,11 @@ namespace asmamd
     accumulate_plane(double *__restrict__ S_out, const CellLane &c, const int kk, const double (&o)[NE])
     {
       double *pl = S_out + kk * (PY * PX) + (P * c.w) * PX + P * c.cl;
+#if defined(ASM_ABLATE) && ASM_ABLATE == 5
+      if (o[3] == 1.2345e300)
+        pl[0] = o[0]; // diagnostic build: no accumulation
+      return;
+#endif
 #pragma unroll
       for (int j = 0; j < N1; ++j)
 #pragma unroll
@@ -378,10 +410,13 @@ namespace asmamd
     }
 
     // carry exchange + accumulation of one layer's cell planes
-    template <int MODE>
+    // On return o holds the gathered src plane of the NEXT layer (k_next >= 0): the loads are
+    // issued as soon as o is dead, so they travel under the barriers and the store epilogue.
+    template <int MODE, bool MASK>
     __device__ __forceinline__ void
     exchange_and_store(const DevGrid &g, const PlaneRole &m, const CellLane &c, const TiledArgs &a, double *__restrict__ S_out,
-                       double *__restrict__ S_carry, double (&o)[NE], const bool active, const bool halo_layer, const int cz)
+                       double *__restrict__ S_carry, double (&o)[NE], const bool active, const bool halo_layer, const int cz,
+                       const int k_next)
     {
       EpilogueOperands<MODE> ops;
       if (!halo_layer)
@@ -402,13 +437,37 @@ namespace asmamd
             cw[e] = active ? o[e] : 0.;
         }
       if (halo_layer)
-        return; // wave-uniform: the halo layer only feeds the carry
+        {
+          // wave-uniform: the halo layer only feeds the carry
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (k_next >= 0)
+            gather_plane<MASK>(g, c, a.src, k_next, o);
+          return;
+        }
+#if defined(ASM_ABLATE) && ASM_ABLATE == 2
+      // diagnostic build: no accumulation, no epilogue (results are wrong)
+      if (active && o[0] == 1.2345e300)
+        a.dst[0] = o[1];
+      if (k_next >= 0)
+        gather_plane<MASK>(g, c, a.src, k_next, o);
+      return;
+#endif
       // even cell rows, then odd cell rows: rows of equal parity share no DoF row
-      if ((c.w & 1) == 0 && active && c.sub < N1 - 1)
-        accumulate_plane(S_out, c, c.sub, o);
+      if ((c.w & 1) == 0)
+        {
+          if (active && c.sub < N1 - 1)
+            accumulate_plane(S_out, c, c.sub, o);
+          if (k_next >= 0)
+            gather_plane<MASK>(g, c, a.src, k_next, o);
+        }
       __syncthreads();
-      if ((c.w & 1) == 1 && active && c.sub < N1 - 1)
-        accumulate_plane(S_out, c, c.sub, o);
+      if ((c.w & 1) == 1)
+        {
+          if (active && c.sub < N1 - 1)
+            accumulate_plane(S_out, c, c.sub, o);
+          if (k_next >= 0)
+            gather_plane<MASK>(g, c, a.src, k_next, o);
+        }
       __syncthreads();
 #pragma unroll
       for (int kk = 0; kk < N1 - 1; ++kk)
@@ -484,6 +543,8 @@ namespace asmamd
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
 
+      double v[NE]; // the lane's plane; reloaded with the next layer inside exchange_and_store
+      gather_plane<false>(g, c, a.src, P * z_first + c.sub, v);
       for (int cz = z_first; cz < Ze; ++cz)
         {
           const bool active = c.cell_xy;
@@ -516,9 +577,8 @@ namespace asmamd
     }               \
   while (0)
 
-          double v[NE], q[NE];
+          double q[NE];
           // ---- layout A: lane = (cell, z plane k); x and y forward sweeps -----------
-          gather_plane<false>(g, c, a.src, P * cz + c.sub, v);
           if (active)
             {
               if (HAS_PRE)
@@ -625,7 +685,8 @@ namespace asmamd
               for (int e = 0; e < NE; ++e)
                 v[e] = 0.;
             }
-          exchange_and_store<MODE>(g, m, c, a, S_out, S_carry, v, active, cz < Zb, cz);
+          exchange_and_store<MODE, false>(g, m, c, a, S_out, S_carry, v, active, cz < Zb, cz,
+                                          cz + 1 < Ze ? P * (cz + 1) + c.sub : -1);
         }
 #undef LOADQ
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
@@ -674,13 +735,14 @@ namespace asmamd
           hy = op.h[1][c.cy + 1];
         }
 
+      double u[NE]; // the lane's plane; reloaded with the next layer inside exchange_and_store
+      gather_plane<true>(g, c, a.src, P * z_first + c.sub, u);
       for (int cz = z_first; cz < Ze; ++cz)
         {
           const bool   active = c.cell_xy;
           const double hz     = op.h[2][cz + 1];
-          double       u[NE], t2[NE];
+          double       t2[NE];
           // ---- layout A: x and y sweeps ------------------------------------------------
-          gather_plane<true>(g, c, a.src, P * cz + c.sub, u);
           if (active)
             {
 #pragma unroll
@@ -727,7 +789,8 @@ namespace asmamd
               for (int e = 0; e < NE; ++e)
                 u[e] = 0.;
             }
-          exchange_and_store<MODE>(g, m, c, a, S_out, S_carry, u, active, cz < Zb, cz);
+          exchange_and_store<MODE, true>(g, m, c, a, S_out, S_carry, u, active, cz < Zb, cz,
+                                         cz + 1 < Ze ? P * (cz + 1) + c.sub : -1);
         }
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
         store_top_plane<MODE>(g, m, c, a, S_out, S_carry);
