@@ -18,6 +18,13 @@
 #include <string>
 #include <vector>
 
+#ifdef ASM_STAMP
+namespace asmamd
+{
+  void tiled_debug_stamps(unsigned long long out[16], bool reset);
+}
+#endif
+
 using namespace asmamd;
 
 static thread_local std::string g_create_error;
@@ -960,6 +967,17 @@ asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms)
   *total_ms = sum;
   return ASM_OK;
 }
+
+#ifdef ASM_STAMP
+// diagnostic builds only (not declared in the public header)
+int
+asm_debug_stamps(asm_ctx *ctx, unsigned long long out[16], int reset)
+{
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  asmamd::tiled_debug_stamps(out, reset != 0);
+  return ASM_OK;
+}
+#endif
 
 int
 asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms)
