@@ -158,9 +158,10 @@ namespace asmamd
       bool lane_ok;          // lanes 60..63 idle
       int  cx, cy;
       bool cell_xy;
-      int      xo[N1], yo[N1]; // storage offsets of the cell's DoF columns / rows
-      unsigned xm, ym;         // existence masks
-      unsigned xd, yd;         // Dirichlet masks
+      // storage offset of the cell's DoF (i, j) = off0 + j stride_y + i, except that the last
+      // column / row may wrap around a periodic seam: xw4 / yw4 hold that correction (0 otherwise)
+      int      off0, xw4, yw4;
+      unsigned xd, yd; // Dirichlet masks of the cell's columns / rows
     };
 
     __device__ __forceinline__ void
@@ -174,18 +175,21 @@ namespace asmamd
       c.cx      = X0 + c.cl;
       c.cy      = Y0 + c.w;
       c.cell_xy = c.lane_ok && cell_computable(g, 0, c.cx) && cell_computable(g, 1, c.cy);
-      c.xm = c.ym = c.xd = c.yd = 0u;
-#pragma unroll
-      for (int i = 0; i < N1; ++i)
+      c.off0 = c.xw4 = c.yw4 = 0;
+      c.xd = c.yd = 0u;
+      if (c.cell_xy)
         {
-          const int  I = P * c.cx + i, J = P * c.cy + i;
-          const bool ex = c.cell_xy && g.exists(0, I), ey = c.cell_xy && g.exists(1, J);
-          c.xo[i] = ex ? (int)(g.store_index(0, I) * g.stride[0]) : 0;
-          c.yo[i] = ey ? (int)(g.store_index(1, J) * g.stride[1]) : 0;
-          c.xm |= (ex ? 1u : 0u) << i;
-          c.ym |= (ey ? 1u : 0u) << i;
-          c.xd |= ((ex && g.dirichlet(0, I)) ? 1u : 0u) << i;
-          c.yd |= ((ey && g.dirichlet(1, J)) ? 1u : 0u) << i;
+          // every DoF of a computable cell exists; columns 0..3 / rows 0..3 are contiguous
+          const int x0 = g.store_index(0, P * c.cx), y0 = g.store_index(1, P * c.cy);
+          c.off0       = (int)(y0 * g.stride[1]) + x0;
+          c.xw4        = g.store_index(0, P * c.cx + P) - (x0 + P);
+          c.yw4        = (int)((g.store_index(1, P * c.cy + P) - (y0 + P)) * g.stride[1]);
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            {
+              c.xd |= (g.dirichlet(0, P * c.cx + i) ? 1u : 0u) << i;
+              c.yd |= (g.dirichlet(1, P * c.cy + i) ? 1u : 0u) << i;
+            }
         }
     }
 
@@ -197,17 +201,22 @@ namespace asmamd
     __device__ __forceinline__ void
     gather_plane(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int K, double (&v)[NE])
     {
-      const double *pl = src + (c.cell_xy ? g.store_index(2, K) * g.stride[2] : 0);
+      const double *pl = src + (c.cell_xy ? g.store_index(2, K) * g.stride[2] : 0) + c.off0;
 #if defined(ASM_ABLATE) && ASM_ABLATE == 4
       for (int e = 0; e < NE; ++e)
         v[e] = 1.0 + e + K; // diagnostic build: no gather
       return;
 #endif
+      const int sy = c.cell_xy ? (int)g.stride[1] : 0;
 #pragma unroll
       for (int j = 0; j < N1; ++j)
+        {
+          const double *row = pl + j * sy + (j == N1 - 1 ? c.yw4 : 0);
 #pragma unroll
-        for (int i = 0; i < N1; ++i)
-          v[j * 5 + i] = pl[c.yo[j] + c.xo[i]];
+          for (int i = 0; i < N1 - 1; ++i)
+            v[j * 5 + i] = row[i];
+          v[j * 5 + N1 - 1] = row[N1 - 1 + c.xw4];
+        }
       if (MASK)
         {
           const bool zd = g.dirichlet(2, K);

@@ -26,9 +26,9 @@ n = 10
 for _ in range(n):
     ctx.cheb_step(x, b)
 lib.asm_debug_stamps(ctx.handle, out, 1)
-names = ["loop/inst", "slice0", "x,y fwd", "transpose", "slice1", "z sweeps", "transpose", "slice2", "y,x bwd", "slice3", "exchange", "", "", "", "", ""]
+names = ["loop top", "x,y fwd (+gather wait)", "transpose A->B", "z sweeps+scale", "transpose B->A", "y,x bwd + weights", "(unused)", "prefetch ops + carry", "acc even + gather issue", "barrier 1", "acc odd + gather issue", "barrier 2", "store epilogue", "barrier 3", "", ""]
 tot = sum(out)
 layers = 17 * n
-for i in range(11):
-    print(f"{names[i]:12s} {out[i] / layers:10.0f} cycles/layer  {100.0 * out[i] / tot:5.1f}%")
+for i in range(14):
+    print(f"{names[i]:26s} {out[i] / layers:10.0f} cycles/layer  {100.0 * out[i] / tot:5.1f}%")
 print("total per layer", tot / layers)
