@@ -47,6 +47,16 @@ namespace asmamd
         }
       return I - ext_lo[d];
     }
+    // same for -n <= I < 2n (anything one patch away from the block): no integer division
+    ASM_HD int store_index_near(const int d, const int I) const
+    {
+      if (wrap[d])
+        {
+          const int n = nc[d] * p;
+          return I < 0 ? I + n : (I >= n ? I - n : I);
+        }
+      return I - ext_lo[d];
+    }
     ASM_HD bool exists(const int d, const int I) const
     {
       return wrap[d] || (I >= ext_lo[d] && I <= ext_hi[d]);

@@ -180,10 +180,10 @@ namespace asmamd
       if (c.cell_xy)
         {
           // every DoF of a computable cell exists; columns 0..3 / rows 0..3 are contiguous
-          const int x0 = g.store_index(0, P * c.cx), y0 = g.store_index(1, P * c.cy);
+          const int x0 = g.store_index_near(0, P * c.cx), y0 = g.store_index_near(1, P * c.cy);
           c.off0       = (int)(y0 * g.stride[1]) + x0;
-          c.xw4        = g.store_index(0, P * c.cx + P) - (x0 + P);
-          c.yw4        = (int)((g.store_index(1, P * c.cy + P) - (y0 + P)) * g.stride[1]);
+          c.xw4        = g.store_index_near(0, P * c.cx + P) - (x0 + P);
+          c.yw4        = (int)((g.store_index_near(1, P * c.cy + P) - (y0 + P)) * g.stride[1]);
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             {
@@ -201,7 +201,7 @@ namespace asmamd
     __device__ __forceinline__ void
     gather_plane(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int K, double (&v)[NE])
     {
-      const double *pl = src + (c.cell_xy ? g.store_index(2, K) * g.stride[2] : 0) + c.off0;
+      const double *pl = src + (c.cell_xy ? g.store_index_near(2, K) * g.stride[2] : 0) + c.off0;
 #if defined(ASM_ABLATE) && ASM_ABLATE == 4
       for (int e = 0; e < NE; ++e)
         v[e] = 1.0 + e + K; // diagnostic build: no gather
@@ -304,7 +304,7 @@ namespace asmamd
       const int I     = I0 + m.lane;
       m.col_in        = m.lane < PX;
       m.col_owned     = m.col_in && g.exists(0, I) && tile_owns(g, 0, m.lane, I, WX);
-      m.col_off       = m.col_owned ? g.store_index(0, I) * g.stride[0] : 0;
+      m.col_off       = m.col_owned ? g.store_index_near(0, I) * g.stride[0] : 0;
       m.col_dirichlet = m.col_owned && g.dirichlet(0, I);
     }
 
@@ -334,7 +334,7 @@ namespace asmamd
     __device__ __forceinline__ long long
     dof_offset(const DevGrid &g, const PlaneRole &m, const int K, const int r)
     {
-      return g.store_index(2, K) * g.stride[2] + m.col_off + row_offset(m, r);
+      return g.store_index_near(2, K) * g.stride[2] + m.col_off + row_offset(m, r);
     }
 
     template <int MODE>
