@@ -137,7 +137,11 @@ namespace asmamd
     // entries scalar operands of the FMAs, so they cost no vector registers
     struct UniformMatrix
     {
-      const double *__restrict__ p;
+      // constant address space: uniform loads from it are scalar (s_load) loads
+      const __attribute__((address_space(4))) double *p;
+      __device__ __forceinline__ explicit UniformMatrix(const double *q)
+        : p((const __attribute__((address_space(4))) double *)q)
+      {}
       __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
     };
 
@@ -585,8 +589,8 @@ namespace asmamd
           // (taken from the row / layer index, not from a lane: lane 0 may hold a cell that does not exist)
           const int iy_u = TENSOR ? f.inst[1][min(max(Y0 + (int)(threadIdx.x >> 6), -1), g.nc[1]) + 1] : 0;
           const int iz_u = TENSOR ? f.inst[2][cz + 1] : 0;
-          const UniformMatrix Uy{f.eig + (long long)__builtin_amdgcn_readfirstlane(iy_u) * EIG},
-            Uz{f.eig + (long long)__builtin_amdgcn_readfirstlane(iz_u) * EIG};
+          const UniformMatrix Uy(f.eig + (long long)__builtin_amdgcn_readfirstlane(iy_u) * EIG),
+            Uz(f.eig + (long long)__builtin_amdgcn_readfirstlane(iz_u) * EIG);
 #define LOADQ(q, d) \
   do                \
     {               \
@@ -741,7 +745,7 @@ namespace asmamd
       double *Tw = S_T + c.w * (2 * 60 * N1);
 
       // reference matrices (row-major [i][j], symmetric): wave-uniform scalar operands
-      const UniformMatrix Mm{op.M_ref}, Km{op.K_ref};
+      const UniformMatrix Mm(op.M_ref), Km(op.K_ref);
       (void)S_tab;
       lds_clear(S_out, S_carry);
       __syncthreads();
