@@ -48,7 +48,8 @@ namespace asmamd
     constexpr int EIG = NE + N1;  // eigen data per 1-D instance
 
     constexpr int LDS_OUT   = 4 * PY * PX;  // four DoF planes
-    constexpr int LDS_T     = TY * 2 * 60 * N1; // transpose buffers, two per wave
+    constexpr int TBUF      = 64 * N1;          // one transpose buffer (all 64 lanes write, no predicate)
+    constexpr int LDS_T     = TY * 2 * TBUF;    // two per wave
     constexpr int LDS_CARRY = TY * WX * NE; // top planes of the previous layer
     constexpr int LDS_TAB   = 16 * EIG;     // eigen tables / reference matrices
     constexpr int LDS_TOTAL = LDS_OUT + LDS_T + LDS_CARRY + LDS_TAB;
@@ -246,25 +247,20 @@ namespace asmamd
       return; // diagnostic build: transposes removed (results are wrong)
 #endif
       double n[NE];
+      // lanes 60..63 hold no cell: they run along unpredicated (their cl = 12 slots exist)
 #pragma unroll
       for (int f = 0; f < N1; ++f)
         {
-          double *buf = Tw + (f & 1) * (60 * N1);
-          if (c.lane_ok)
-            {
+          double *buf = Tw + (f & 1) * TBUF;
 #pragma unroll
-              for (int s = 0; s < N1; ++s)
-                buf[c.lane * N1 + s] = v[s * 5 + f];
-            }
+          for (int s = 0; s < N1; ++s)
+            buf[c.lane * N1 + s] = v[s * 5 + f];
           // the partner lanes' stores must be visible: LDS executes a wave's
           // instructions in order; keep the compiler from moving the loads up
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (c.lane_ok)
-            {
 #pragma unroll
-              for (int s = 0; s < N1; ++s)
-                n[s * 5 + f] = buf[(c.cl * N1 + s) * N1 + c.sub];
-            }
+          for (int s = 0; s < N1; ++s)
+            n[s * 5 + f] = buf[(c.cl * N1 + s) * N1 + c.sub];
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -555,7 +551,7 @@ namespace asmamd
       role_setup(g, P * X0, P * Y0, m);
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
-      double *Tw = S_T + c.w * (2 * 60 * N1);
+      double *Tw = S_T + c.w * (2 * TBUF);
 
       // eigen tables of tensor-product meshes live in LDS (the launcher checks n_inst <= 16)
       if (TENSOR)
@@ -742,7 +738,7 @@ namespace asmamd
       role_setup(g, P * X0, P * Y0, m);
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
-      double *Tw = S_T + c.w * (2 * 60 * N1);
+      double *Tw = S_T + c.w * (2 * TBUF);
 
       // reference matrices (row-major [i][j], symmetric): wave-uniform scalar operands
       const UniformMatrix Mm(op.M_ref), Km(op.K_ref);
