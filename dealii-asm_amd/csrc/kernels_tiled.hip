@@ -565,6 +565,7 @@ namespace asmamd
 
       double v[NE]; // the lane's plane; reloaded with the next layer inside exchange_and_store
       gather_plane<false>(g, c, a.src, P * z_first + c.sub, v);
+      const int cxs = c.cell_xy ? c.cx : 0, cys = c.cell_xy ? c.cy : 0; // table rows that exist
       for (int cz = z_first; cz < Ze; ++cz)
         {
           const bool active = c.cell_xy;
@@ -587,6 +588,12 @@ namespace asmamd
           const int iz_u = TENSOR ? f.inst[2][cz + 1] : 0;
           const UniformMatrix Uy(f.eig + (long long)__builtin_amdgcn_readfirstlane(iy_u) * EIG),
             Uz(f.eig + (long long)__builtin_amdgcn_readfirstlane(iz_u) * EIG);
+          // the x matrix is wave-uniform too unless the cell row touches a boundary column
+          unsigned long long amask = __ballot(active);
+          const int          lane0 = amask ? __ffsll((long long)amask) - 1 : 0;
+          const int          ix_u  = __builtin_amdgcn_readlane(ix, lane0);
+          const bool         x_uniform = TENSOR && __all(!active || ix == ix_u);
+          const UniformMatrix Ux(f.eig + (long long)ix_u * EIG);
 #define LOADQ(q, d) \
   do                \
     {               \
@@ -598,112 +605,100 @@ namespace asmamd
   while (0)
 
           double q[NE];
+          // Lanes without a cell run along unpredicated on harmless data (table row 0, src
+          // offset 0); nothing they compute is ever accumulated or carried.
           // ---- layout A: lane = (cell, z plane k); x and y forward sweeps -----------
-          if (active)
+          if (HAS_PRE)
             {
-              if (HAS_PRE)
+              const double wz = f.w_pre[2][(cz + 1) * N1 + c.sub];
+#pragma unroll
+              for (int j = 0; j < N1; ++j)
                 {
-                  const double wz = f.w_pre[2][(cz + 1) * N1 + c.sub];
-                  double       wx[N1], wy[N1];
+                  const double wyz = f.w_pre[1][(cys + 1) * N1 + j] * wz;
 #pragma unroll
                   for (int i = 0; i < N1; ++i)
-                    {
-                      wx[i] = f.w_pre[0][(c.cx + 1) * N1 + i];
-                      wy[i] = f.w_pre[1][(c.cy + 1) * N1 + i] * wz;
-                    }
-#pragma unroll
-                  for (int j = 0; j < N1; ++j)
-#pragma unroll
-                    for (int i = 0; i < N1; ++i)
-                      v[j * 5 + i] *= wx[i] * wy[j];
+                    v[j * 5 + i] *= f.w_pre[0][(cxs + 1) * N1 + i] * wyz;
                 }
+            }
+          if (x_uniform)
+            sweep_fast<true>(v, Ux);
+          else
+            {
               LOADQ(q, ex);
               sweep_fast<true>(v, q);
-              if (TENSOR)
-                sweep_slow<true>(v, Uy);
-              else
-                {
-                  LOADQ(q, ey);
-                  sweep_slow<true>(v, q);
-                }
+            }
+          if (TENSOR)
+            sweep_slow<true>(v, Uy);
+          else
+            {
+              LOADQ(q, ey);
+              sweep_slow<true>(v, q);
             }
           // ---- layout B: lane = (cell, y index b), v[c*5 + a]; z sweeps + scaling ----
           transpose5(v, Tw, c);
-          if (active)
+          if (TENSOR)
+            sweep_slow<true>(v, Uz);
+          else
             {
-              if (TENSOR)
-                sweep_slow<true>(v, Uz);
-              else
-                {
-                  LOADQ(q, ez);
-                  sweep_slow<true>(v, q);
-                }
-              if (f.inv_table != nullptr)
-                {
-                  const double *inv =
-                    f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) + c.sub * N1;
-#pragma unroll
-                  for (int cc = 0; cc < N1; ++cc)
-#pragma unroll
-                    for (int aa = 0; aa < N1; ++aa)
-                      v[cc * 5 + aa] *= inv[cc * NE + aa];
-                }
-              else
-                {
-                  const double lyb = TENSOR ? eyl[NE + c.sub] : eyg[NE + c.sub];
-#pragma unroll
-                  for (int cc = 0; cc < N1; ++cc)
-#pragma unroll
-                    for (int aa = 0; aa < N1; ++aa)
-                      {
-                        // reciprocal with two Newton steps (full double precision)
-                        const double sm = (TENSOR ? exl[NE + aa] : exg[NE + aa]) + (lyb + (TENSOR ? ezl[NE + cc] : ezg[NE + cc]));
-                        double       r  = __builtin_amdgcn_rcp(sm);
-                        r               = fma(fma(-sm, r, 1.0), r, r);
-                        r               = fma(fma(-sm, r, 1.0), r, r);
-                        v[cc * 5 + aa] *= r;
-                      }
-                }
-              if (TENSOR)
-                sweep_slow<false>(v, Uz);
-              else
-                sweep_slow<false>(v, q);
+              LOADQ(q, ez);
+              sweep_slow<true>(v, q);
             }
-          // ---- back to layout A; y and x backward sweeps, post weights ---------------
-          transpose5(v, Tw, c);
-          if (active)
+          if (f.inv_table != nullptr)
             {
-              if (TENSOR)
-                sweep_slow<false>(v, Uy);
-              else
-                {
-                  LOADQ(q, ey);
-                  sweep_slow<false>(v, q);
-                }
-              LOADQ(q, ex);
-              sweep_fast<false>(v, q);
-              if (HAS_POST)
-                {
-                  const double wz = f.w_post[2][(cz + 1) * N1 + c.sub];
-                  double       wx[N1], wy[N1];
+              const double *inv = f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) + c.sub * N1;
 #pragma unroll
-                  for (int i = 0; i < N1; ++i)
-                    {
-                      wx[i] = f.w_post[0][(c.cx + 1) * N1 + i];
-                      wy[i] = f.w_post[1][(c.cy + 1) * N1 + i] * wz;
-                    }
+              for (int cc = 0; cc < N1; ++cc)
 #pragma unroll
-                  for (int j = 0; j < N1; ++j)
-#pragma unroll
-                    for (int i = 0; i < N1; ++i)
-                      v[j * 5 + i] *= wx[i] * wy[j];
-                }
+                for (int aa = 0; aa < N1; ++aa)
+                  v[cc * 5 + aa] *= inv[cc * NE + aa];
             }
           else
             {
+              const double lyb = TENSOR ? eyl[NE + c.sub] : eyg[NE + c.sub];
 #pragma unroll
-              for (int e = 0; e < NE; ++e)
-                v[e] = 0.;
+              for (int cc = 0; cc < N1; ++cc)
+#pragma unroll
+                for (int aa = 0; aa < N1; ++aa)
+                  {
+                    // reciprocal with two Newton steps (full double precision)
+                    const double sm = (TENSOR ? exl[NE + aa] : exg[NE + aa]) + (lyb + (TENSOR ? ezl[NE + cc] : ezg[NE + cc]));
+                    double       r  = __builtin_amdgcn_rcp(sm);
+                    r               = fma(fma(-sm, r, 1.0), r, r);
+                    r               = fma(fma(-sm, r, 1.0), r, r);
+                    v[cc * 5 + aa] *= r;
+                  }
+            }
+          if (TENSOR)
+            sweep_slow<false>(v, Uz);
+          else
+            sweep_slow<false>(v, q);
+          // ---- back to layout A; y and x backward sweeps, post weights ---------------
+          transpose5(v, Tw, c);
+          if (TENSOR)
+            sweep_slow<false>(v, Uy);
+          else
+            {
+              LOADQ(q, ey);
+              sweep_slow<false>(v, q);
+            }
+          if (x_uniform)
+            sweep_fast<false>(v, Ux);
+          else
+            {
+              LOADQ(q, ex);
+              sweep_fast<false>(v, q);
+            }
+          if (HAS_POST)
+            {
+              const double wz = f.w_post[2][(cz + 1) * N1 + c.sub];
+#pragma unroll
+              for (int j = 0; j < N1; ++j)
+                {
+                  const double wyz = f.w_post[1][(cys + 1) * N1 + j] * wz;
+#pragma unroll
+                  for (int i = 0; i < N1; ++i)
+                    v[j * 5 + i] *= f.w_post[0][(cxs + 1) * N1 + i] * wyz;
+                }
             }
           exchange_and_store<MODE, false>(g, m, c, a, S_out, S_carry, v, active, cz < Zb, cz,
                                           cz + 1 < Ze ? P * (cz + 1) + c.sub : -1);
