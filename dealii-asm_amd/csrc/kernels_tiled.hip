@@ -757,53 +757,42 @@ namespace asmamd
           const bool   active = c.cell_xy;
           const double hz     = op.h[2][cz + 1];
           double       t2[NE];
+          // lanes without a cell run along unpredicated; nothing of theirs is accumulated or carried
           // ---- layout A: x and y sweeps ------------------------------------------------
-          if (active)
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            t2[e] = u[e];
+          sweep_fast<true>(t2, Km); // t2 = Kx u
+          sweep_fast<true>(u, Mm);  // u  = Mx u
+          const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
+          // column by column: t2 <- alpha My t2 + beta Ky u  (needs Mz),  u <- gamma My u  (needs Kz)
+#pragma unroll
+          for (int f = 0; f < N1; ++f)
             {
-#pragma unroll
-              for (int e = 0; e < NE; ++e)
-                t2[e] = u[e];
-              sweep_fast<true>(t2, Km); // t2 = Kx u
-              sweep_fast<true>(u, Mm);  // u  = Mx u
-              const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
-              // column by column: t2 <- alpha My t2 + beta Ky u  (needs Mz),  u <- gamma My u  (needs Kz)
-#pragma unroll
-              for (int f = 0; f < N1; ++f)
-                {
-                  double k0 = u[0 * 5 + f], k1 = u[1 * 5 + f], k2 = u[2 * 5 + f], k3 = u[3 * 5 + f], k4 = u[4 * 5 + f];
-                  line5<true>(k0, k1, k2, k3, k4, Km); // Ky (Mx u)
-                  line5<true>(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f], Mm);
-                  line5<true>(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f], Mm);
-                  t2[0 * 5 + f] = fma(beta, k0, alpha * t2[0 * 5 + f]);
-                  t2[1 * 5 + f] = fma(beta, k1, alpha * t2[1 * 5 + f]);
-                  t2[2 * 5 + f] = fma(beta, k2, alpha * t2[2 * 5 + f]);
-                  t2[3 * 5 + f] = fma(beta, k3, alpha * t2[3 * 5 + f]);
-                  t2[4 * 5 + f] = fma(beta, k4, alpha * t2[4 * 5 + f]);
-                  u[0 * 5 + f] *= gamma;
-                  u[1 * 5 + f] *= gamma;
-                  u[2 * 5 + f] *= gamma;
-                  u[3 * 5 + f] *= gamma;
-                  u[4 * 5 + f] *= gamma;
-                }
+              double k0 = u[0 * 5 + f], k1 = u[1 * 5 + f], k2 = u[2 * 5 + f], k3 = u[3 * 5 + f], k4 = u[4 * 5 + f];
+              line5<true>(k0, k1, k2, k3, k4, Km); // Ky (Mx u)
+              line5<true>(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f], Mm);
+              line5<true>(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f], Mm);
+              t2[0 * 5 + f] = fma(beta, k0, alpha * t2[0 * 5 + f]);
+              t2[1 * 5 + f] = fma(beta, k1, alpha * t2[1 * 5 + f]);
+              t2[2 * 5 + f] = fma(beta, k2, alpha * t2[2 * 5 + f]);
+              t2[3 * 5 + f] = fma(beta, k3, alpha * t2[3 * 5 + f]);
+              t2[4 * 5 + f] = fma(beta, k4, alpha * t2[4 * 5 + f]);
+              u[0 * 5 + f] *= gamma;
+              u[1 * 5 + f] *= gamma;
+              u[2 * 5 + f] *= gamma;
+              u[3 * 5 + f] *= gamma;
+              u[4 * 5 + f] *= gamma;
             }
           // ---- layout B: z sweeps ------------------------------------------------------
           transpose5(t2, Tw, c);
           transpose5(u, Tw, c);
-          if (active)
-            {
-              sweep_slow<true>(u, Km);  // Kz (My Mx u)
-              sweep_slow<true>(t2, Mm); // Mz (...)
+          sweep_slow<true>(u, Km);  // Kz (My Mx u)
+          sweep_slow<true>(t2, Mm); // Mz (...)
 #pragma unroll
-              for (int e = 0; e < NE; ++e)
-                u[e] += t2[e];
-            }
+          for (int e = 0; e < NE; ++e)
+            u[e] += t2[e];
           transpose5(u, Tw, c);
-          if (!active)
-            {
-#pragma unroll
-              for (int e = 0; e < NE; ++e)
-                u[e] = 0.;
-            }
           exchange_and_store<MODE, true>(g, m, c, a, S_out, S_carry, u, active, cz < Zb, cz,
                                          cz + 1 < Ze ? P * (cz + 1) + c.sub : -1);
         }
