@@ -192,14 +192,27 @@ def main():
                     "GBps": bytes_per_launch / (ms / n * 1e-3) / 1e9,
                 }
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+        # HBM traffic per launch: measured separately with rocprofv3 PMC passes (bench.py cannot
+        # run the profiler on itself); only reported when the committed measurement is for
+        # exactly this workload and kernel family, else null
+        traffic, traffic_src = None, None
+        key = f"{args.workload}:{cells[0]}x{cells[1]}x{cells[2]}:{ctx.kernel_variant()}:{args.what}:{args.degree}"
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            if world == 1 and key in tr:
+                traffic, traffic_src = tr[key][dom], tr[key]["source"]
+        except OSError:
+            pass
+        lap_variant = "generic" if args.workload == "kershaw" else ctx.kernel_variant()
         roofline = {
             "bound": "hbm",
-            "kernel": {"laplace": "Laplace sweep", "fdm": "FDM Schwarz sweep"}[dom] + f" ({ctx.kernel_variant()})",
+            "kernel": {"laplace": f"Laplace sweep ({lap_variant})", "fdm": f"FDM Schwarz sweep ({ctx.kernel_variant()})"}[dom],
             "achieved": kernels[dom]["GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "avg_launch_ms": kernels[dom]["avg_ms"],
             "kernels": kernels,
         }
