@@ -48,21 +48,43 @@ def algorithmic_bytes_per_dof(degree, what):
 
 
 def cpu_baseline(args, pkg):
-    """numpy restatement (oracle/asm_oracle.py, kind 'port') of the same smoother
-    application, timed on one host core on a bounded sample of the workload."""
+    """The same smoother application on the host cores, on a bounded sample of the workload.
+    Cartesian workloads: the threaded C++ restatement oracle/asm_oracle_cpu.cc (kind "port",
+    checked against the numpy oracle in tests/test_oracle_cpu_port.py), all host threads.
+    Kershaw: the numpy oracle on one core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import asm_oracle as orc
 
+    if args.workload != "kershaw":
+        import asm_oracle_cpu
+
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        nc = (40, 40, 40) if args.workload == "cart_dirichlet" else (48, 32, 32)
+        sm = asm_oracle_cpu.CpuSmoother(nc, args.workload == "cart_periodic", degree=args.degree, lambda_max=1.7, n_threads=threads)
+        b = np.ones(sm.n_dofs)
+        x = sm.step(np.zeros(sm.n_dofs), b)  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            x = sm.step(x, b, reps=2)
+            reps += 2
+            el = time.perf_counter() - t0
+            if el > 10.0 or reps >= 400:
+                break
+        return {
+            "value": sm.n_dofs * reps / el,
+            "unit": "DoF/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} cells p=4 "
+            f"({sm.n_dofs} DoFs), C++ restatement oracle/asm_oracle_cpu.cc, {threads} threads",
+        }
     nc = (12, 12, 12)
-    bc = orc.PERIODIC if args.workload == "cart_periodic" else orc.DIRICHLET
-    mapfn = (lambda pts: orc.kershaw(0.3, 0.3, pts)) if args.workload == "kershaw" else None
-    mesh = orc.Mesh(nc, 4, [bc] * 3, mapfn=mapfn)
+    mesh = orc.Mesh(nc, 4, [orc.DIRICHLET] * 3, mapfn=lambda pts: orc.kershaw(0.3, 0.3, pts))
     op = orc.LaplaceOperator(mesh)
     prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
     cheb = orc.Chebyshev(op, prec, degree=args.degree, lambda_max=1.8)
     b = np.ones(mesh.n_dofs)
-    x = np.zeros(mesh.n_dofs)
-    x = cheb.step(x, b)  # warm-up
+    x = cheb.step(np.zeros(mesh.n_dofs), b)  # warm-up
     reps, t0 = 0, time.perf_counter()
     while True:
         x = cheb.step(x, b)
@@ -75,7 +97,7 @@ def cpu_baseline(args, pkg):
         "unit": "DoF/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} cells p=4 "
+        "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} Kershaw cells p=4 "
         f"({mesh.n_dofs} DoFs), numpy oracle, 1 thread",
     }
 

@@ -1,0 +1,335 @@
+// CPU restatement (C++, threaded) of one Chebyshev + FDM additive-Schwarz smoother
+// application for Cartesian meshes, degree 4, n_overlap = 1, "post" weights.
+//
+// *** TEST INFRASTRUCTURE ONLY *** -- used by tests/ (checked against the numpy oracle)
+// and by the cpu_baseline leg of bench.py; the product path never links or loads it.
+//
+// It follows the reference's sweep structure (not its source):
+//   * cells are processed in SIMD batches of 8, one cell per lane, like deal.II's
+//     VectorizedArray<double> cell batches (include/operator.h:1335-1351);
+//   * A: gather -> sum-factorised evaluate(gradients) (interpolation to the Gauss points,
+//     collocation derivative) -> Cartesian J^-1 J^-T detJ w -> integrate -> scatter-add
+//     (do_cell_integral_local_base, include/operator.h:866-875);
+//   * P: gather -> 3 sweeps with Q^T, scaling by 1/(lx+ly+lz), 3 sweeps with Q, weights,
+//     scatter-add (cell_operation_normal, include/matrix_free.h:1023-1062);
+//   * Chebyshev updates as in PreconditionChebyshev (deal.II) for the first-kind polynomial;
+//   * threads take cells of one colour (2x2x2 parity) at a time, the shared-memory
+//     counterpart of the reference's one-MPI-rank-per-core runs.
+// Tables (1-D basis, eigen-decompositions, weights) are computed by oracle/asm_oracle.py
+// and passed in, so this file contains the sweeps only.
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace
+{
+  constexpr int P = 4, N1 = 5, NE = 125, VL = 8;
+
+  struct Problem
+  {
+    int           nc[3], nu[3], periodic[3];
+    double        h[3];
+    const double *N, *Dc, *wq;             // [q][i], [q][r], [q]
+    const int *   inst[3];                 // [nc[d]]
+    const double *eig;                     // [n_inst][30]
+    const double *wpost[3];                // [nc[d]][5]
+  };
+
+  inline long
+  dof(const Problem &p, int I, int J, int K)
+  {
+    if (p.periodic[0] && I == p.nu[0])
+      I = 0;
+    if (p.periodic[1] && J == p.nu[1])
+      J = 0;
+    if (p.periodic[2] && K == p.nu[2])
+      K = 0;
+    return I + (long)p.nu[0] * (J + (long)p.nu[1] * K);
+  }
+  inline bool
+  constrained(const Problem &p, int d, int I)
+  {
+    return !p.periodic[d] && (I == 0 || I == p.nc[d] * P);
+  }
+
+  // out[a][.] = sum_i M[a*5+i] in[i][.] along direction d of a [5][5][5][VL] tile
+  template <bool TRANSPOSE>
+  inline void
+  sweep(const double *M, const int d, double (*t)[VL])
+  {
+    const int stride = d == 0 ? 1 : (d == 1 ? N1 : N1 * N1);
+    for (int o2 = 0; o2 < N1; ++o2)
+      for (int o1 = 0; o1 < N1; ++o1)
+        {
+          const int base = d == 0 ? (o2 * N1 + o1) * N1 : (d == 1 ? o2 * N1 * N1 + o1 : o2 * N1 + o1);
+          double    in[N1][VL], out[N1][VL];
+          for (int i = 0; i < N1; ++i)
+            for (int v = 0; v < VL; ++v)
+              in[i][v] = t[base + i * stride][v];
+          for (int a = 0; a < N1; ++a)
+            {
+              for (int v = 0; v < VL; ++v)
+                out[a][v] = 0.;
+              for (int i = 0; i < N1; ++i)
+                {
+                  const double m = TRANSPOSE ? M[i * N1 + a] : M[a * N1 + i];
+                  for (int v = 0; v < VL; ++v)
+                    out[a][v] += m * in[i][v];
+                }
+            }
+          for (int i = 0; i < N1; ++i)
+            for (int v = 0; v < VL; ++v)
+              t[base + i * stride][v] = out[i][v];
+        }
+  }
+
+  // same with a different matrix per lane: M[v] points to a 5x5 matrix Q[i][a]
+  template <bool FWD>
+  inline void
+  sweep_q(const double *const *Q, const int d, double (*t)[VL])
+  {
+    const int stride = d == 0 ? 1 : (d == 1 ? N1 : N1 * N1);
+    for (int o2 = 0; o2 < N1; ++o2)
+      for (int o1 = 0; o1 < N1; ++o1)
+        {
+          const int base = d == 0 ? (o2 * N1 + o1) * N1 : (d == 1 ? o2 * N1 * N1 + o1 : o2 * N1 + o1);
+          double    in[N1][VL], out[N1][VL];
+          for (int i = 0; i < N1; ++i)
+            for (int v = 0; v < VL; ++v)
+              in[i][v] = t[base + i * stride][v];
+          for (int a = 0; a < N1; ++a)
+            {
+              for (int v = 0; v < VL; ++v)
+                out[a][v] = 0.;
+              for (int i = 0; i < N1; ++i)
+                for (int v = 0; v < VL; ++v)
+                  out[a][v] += (FWD ? Q[v][i * N1 + a] : Q[v][a * N1 + i]) * in[i][v];
+            }
+          for (int i = 0; i < N1; ++i)
+            for (int v = 0; v < VL; ++v)
+              t[base + i * stride][v] = out[i][v];
+        }
+  }
+
+  struct Batch
+  {
+    int  n;            // active lanes
+    int  c[VL][3];     // cell coordinates
+  };
+
+  template <bool MASK>
+  inline void
+  gather(const Problem &p, const Batch &bt, const double *src, double (*t)[VL])
+  {
+    for (int k = 0; k < N1; ++k)
+      for (int j = 0; j < N1; ++j)
+        for (int i = 0; i < N1; ++i)
+          for (int v = 0; v < VL; ++v)
+            {
+              double val = 0.;
+              if (v < bt.n)
+                {
+                  const int I = P * bt.c[v][0] + i, J = P * bt.c[v][1] + j, K = P * bt.c[v][2] + k;
+                  if (!(MASK && (constrained(p, 0, I) || constrained(p, 1, J) || constrained(p, 2, K))))
+                    val = src[dof(p, I, J, K)];
+                }
+              t[(k * N1 + j) * N1 + i][v] = val;
+            }
+  }
+
+  inline void
+  scatter_add(const Problem &p, const Batch &bt, const double (*t)[VL], double *dst, const double sign)
+  {
+    for (int k = 0; k < N1; ++k)
+      for (int j = 0; j < N1; ++j)
+        for (int i = 0; i < N1; ++i)
+          for (int v = 0; v < bt.n; ++v)
+            {
+              const int I = P * bt.c[v][0] + i, J = P * bt.c[v][1] + j, K = P * bt.c[v][2] + k;
+              if (!(constrained(p, 0, I) || constrained(p, 1, J) || constrained(p, 2, K)))
+                dst[dof(p, I, J, K)] += sign * t[(k * N1 + j) * N1 + i][v];
+            }
+  }
+
+  // dst += sign * A_cell src   (sum factorisation, 12 sweeps)
+  void
+  laplace_batch(const Problem &p, const Batch &bt, const double *src, double *dst, const double sign)
+  {
+    alignas(64) double u[NE][VL], g[3][NE][VL];
+    gather<true>(p, bt, src, u);
+    for (int d = 0; d < 3; ++d)
+      sweep<false>(p.N, d, u); // values at the quadrature points
+    const double det = p.h[0] * p.h[1] * p.h[2];
+    for (int d = 0; d < 3; ++d)
+      {
+        std::memcpy(g[d], u, sizeof(u));
+        sweep<false>(p.Dc, d, g[d]); // reference gradient component d
+        for (int k = 0; k < N1; ++k)
+          for (int j = 0; j < N1; ++j)
+            for (int i = 0; i < N1; ++i)
+              {
+                const double f = det * p.wq[i] * p.wq[j] * p.wq[k] / (p.h[d] * p.h[d]);
+                for (int v = 0; v < VL; ++v)
+                  g[d][(k * N1 + j) * N1 + i][v] *= f;
+              }
+        sweep<true>(p.Dc, d, g[d]);
+      }
+    for (int e = 0; e < NE; ++e)
+      for (int v = 0; v < VL; ++v)
+        u[e][v] = g[0][e][v] + g[1][e][v] + g[2][e][v];
+    for (int d = 0; d < 3; ++d)
+      sweep<true>(p.N, d, u);
+    scatter_add(p, bt, u, dst, sign);
+  }
+
+  // dst += P_cell^-1 src
+  void
+  fdm_batch(const Problem &p, const Batch &bt, const double *src, double *dst)
+  {
+    alignas(64) double t[NE][VL];
+    gather<false>(p, bt, src, t);
+    const double *Q[3][VL], *lam[3][VL], *w[3][VL];
+    for (int d = 0; d < 3; ++d)
+      for (int v = 0; v < VL; ++v)
+        {
+          const int c = bt.c[v < bt.n ? v : 0][d];
+          Q[d][v]     = p.eig + (long)p.inst[d][c] * 30;
+          lam[d][v]   = Q[d][v] + 25;
+          w[d][v]     = p.wpost[d] + (long)c * N1;
+        }
+    for (int d = 0; d < 3; ++d)
+      sweep_q<true>(Q[d], d, t);
+    for (int k = 0; k < N1; ++k)
+      for (int j = 0; j < N1; ++j)
+        for (int i = 0; i < N1; ++i)
+          for (int v = 0; v < VL; ++v)
+            t[(k * N1 + j) * N1 + i][v] /= lam[0][v][i] + (lam[1][v][j] + lam[2][v][k]);
+    for (int d = 0; d < 3; ++d)
+      sweep_q<false>(Q[d], d, t);
+    for (int k = 0; k < N1; ++k)
+      for (int j = 0; j < N1; ++j)
+        for (int i = 0; i < N1; ++i)
+          for (int v = 0; v < VL; ++v)
+            t[(k * N1 + j) * N1 + i][v] *= w[0][v][i] * (w[1][v][j] * w[2][v][k]);
+    scatter_add(p, bt, t, dst, 1.0);
+  }
+
+  // run f(batch) over all cells, colour by colour, batches split over threads
+  template <typename F>
+  void
+  cell_loop(const Problem &p, const int n_threads, F &&f)
+  {
+    for (int colour = 0; colour < 8; ++colour)
+      {
+        std::vector<Batch> batches;
+        for (int cz = (colour >> 2) & 1; cz < p.nc[2]; cz += 2)
+          for (int cy = (colour >> 1) & 1; cy < p.nc[1]; cy += 2)
+            {
+              Batch bt;
+              bt.n = 0;
+              for (int cx = colour & 1; cx < p.nc[0]; cx += 2)
+                {
+                  bt.c[bt.n][0] = cx;
+                  bt.c[bt.n][1] = cy;
+                  bt.c[bt.n][2] = cz;
+                  if (++bt.n == VL)
+                    {
+                      batches.push_back(bt);
+                      bt.n = 0;
+                    }
+                }
+              if (bt.n)
+                batches.push_back(bt);
+            }
+        std::vector<std::thread> pool;
+        const size_t             nb = batches.size();
+        for (int th = 0; th < n_threads; ++th)
+          pool.emplace_back([&, th]() {
+            for (size_t i = nb * th / n_threads; i < nb * (th + 1) / n_threads; ++i)
+              f(batches[i]);
+          });
+        for (auto &t : pool)
+          t.join();
+      }
+  }
+} // namespace
+
+extern "C" {
+
+// x <- Chebyshev step (degree k, first kind) with the FDM preconditioner, `reps` times
+int
+oracle_cpu_cheb_step(const int *nc, const int *periodic, const double *h, const double *N, const double *Dc, const double *wq,
+                     const int *inst_x, const int *inst_y, const int *inst_z, const double *eig, const double *wpost_x,
+                     const double *wpost_y, const double *wpost_z, const int degree, const double theta, const double delta,
+                     double *x, const double *b, const int n_threads, const int reps)
+{
+  Problem p;
+  long    n = 1;
+  for (int d = 0; d < 3; ++d)
+    {
+      p.nc[d]       = nc[d];
+      p.periodic[d] = periodic[d];
+      p.nu[d]       = nc[d] * P + (periodic[d] ? 0 : 1);
+      p.h[d]        = h[d];
+      n *= p.nu[d];
+      if (periodic[d] && (nc[d] % 2))
+        return 1; // the 2x2x2 colouring needs an even number of cells in periodic directions
+    }
+  p.N        = N;
+  p.Dc       = Dc;
+  p.wq       = wq;
+  p.inst[0]  = inst_x;
+  p.inst[1]  = inst_y;
+  p.inst[2]  = inst_z;
+  p.eig      = eig;
+  p.wpost[0] = wpost_x;
+  p.wpost[1] = wpost_y;
+  p.wpost[2] = wpost_z;
+  std::vector<char> con(n, 0);
+  for (int K = 0; K < p.nu[2]; ++K)
+    for (int J = 0; J < p.nu[1]; ++J)
+      for (int I = 0; I < p.nu[0]; ++I)
+        con[I + (long)p.nu[0] * (J + (long)p.nu[1] * K)] = constrained(p, 0, I) || constrained(p, 1, J) || constrained(p, 2, K);
+
+  std::vector<double> r(n), t(n), xo(n), xn(n);
+  const auto residual = [&](const double *xx) {
+    // r = b - A x, identity rows on constrained DoFs (matrix_free_internal.h:247-255)
+    for (long i = 0; i < n; ++i)
+      r[i] = con[i] ? b[i] - xx[i] : b[i];
+    cell_loop(p, n_threads, [&](const Batch &bt) { laplace_batch(p, bt, xx, r.data(), -1.0); });
+  };
+  const auto precondition = [&]() {
+    for (long i = 0; i < n; ++i)
+      t[i] = con[i] ? r[i] : 0.;
+    cell_loop(p, n_threads, [&](const Batch &bt) { fdm_batch(p, bt, r.data(), t.data()); });
+  };
+  for (int rep = 0; rep < reps; ++rep)
+    {
+      residual(x);
+      precondition();
+      for (long i = 0; i < n; ++i)
+        {
+          xo[i] = x[i];
+          x[i] += t[i] / theta;
+        }
+      double       rhok  = delta / theta;
+      const double sigma = theta / delta;
+      for (int k = 1; k < degree; ++k)
+        {
+          const double rhokp = 1. / (2. * sigma - rhok);
+          const double f1 = rhokp * rhok, f2 = 2. * rhokp / delta;
+          rhok = rhokp;
+          residual(x);
+          precondition();
+          for (long i = 0; i < n; ++i)
+            {
+              xn[i] = x[i] + f1 * (x[i] - xo[i]) + f2 * t[i];
+              xo[i] = x[i];
+              x[i]  = xn[i];
+            }
+        }
+    }
+  return 0;
+}
+}

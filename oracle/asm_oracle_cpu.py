@@ -1,0 +1,76 @@
+"""ctypes driver of oracle/asm_oracle_cpu.cc (TEST INFRASTRUCTURE ONLY: tests/ and the
+cpu_baseline leg of bench.py).  Tables come from the numpy oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import asm_oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "liboracle_cpu.so")
+
+
+def _ptr(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class CpuSmoother:
+    """Chebyshev(k) + FDM (n_overlap=1, post weights) on a Cartesian box, degree 4."""
+
+    def __init__(self, nc, periodic, extent=(1.0, 1.0, 1.0), degree=3, lambda_max=1.8, smoothing_range=20.0, n_threads=1):
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} missing: run `make -C oracle`")
+        self.lib = C.CDLL(LIB)
+        self.nc = np.array(nc, dtype=np.int32)
+        self.periodic = np.array([1 if periodic else 0] * 3, dtype=np.int32)
+        self.h = np.array([extent[d] / nc[d] for d in range(3)], dtype=np.float64)
+        self.degree, self.n_threads = degree, n_threads
+        max_ev = 1.2 * lambda_max
+        min_ev = max_ev / smoothing_range
+        self.theta, self.delta = 0.5 * (max_ev + min_ev), 0.5 * (max_ev - min_ev)
+        b = orc.Basis1D(4)
+        self.N = np.ascontiguousarray(b.N)
+        _, Dc = orc.lagrange_eval(b.xq, b.xq)
+        self.Dc = np.ascontiguousarray(Dc)
+        self.wq = np.ascontiguousarray(b.wq)
+        # 1-D FDM instances and weights per direction (tensor-product structure of a box)
+        eig, self.inst, self.wpost = [], [], []
+        cache = {}
+        for d in range(3):
+            inst = np.zeros(nc[d], dtype=np.int32)
+            w = np.zeros((nc[d], 5))
+            for c in range(nc[d]):
+                lo = "internal" if (periodic or c > 0) else orc.DIRICHLET
+                hi = "internal" if (periodic or c < nc[d] - 1) else orc.DIRICHLET
+                h3 = (self.h[d] if lo == "internal" else 0.0, self.h[d], self.h[d] if hi == "internal" else 0.0)
+                key = (h3, lo, hi)
+                if key not in cache:
+                    M, K = orc.fdm_matrices_element(b, h3, lo, hi, 1)
+                    lam, Q = orc.fdm_eigen(M, K)
+                    cache[key] = len(eig)
+                    eig.append(np.concatenate([Q.reshape(-1), lam]))
+                inst[c] = cache[key]
+                for i in range(5):
+                    valence = 2.0 if (i in (0, 4)) else 1.0
+                    if i == 0 and lo != "internal":
+                        valence = 0.0
+                    if i == 4 and hi != "internal":
+                        valence = 0.0
+                    w[c, i] = 0.0 if valence == 0 else 1.0 / valence
+            self.inst.append(inst)
+            self.wpost.append(np.ascontiguousarray(w))
+        self.eig = np.ascontiguousarray(np.array(eig))
+        self.n_dofs = int(np.prod([nc[d] * 4 + (0 if periodic else 1) for d in range(3)]))
+
+    def step(self, x, b, reps=1):
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        err = self.lib.oracle_cpu_cheb_step(
+            _ptr(self.nc, C.c_int32), _ptr(self.periodic, C.c_int32), _ptr(self.h), _ptr(self.N), _ptr(self.Dc), _ptr(self.wq),
+            _ptr(self.inst[0], C.c_int32), _ptr(self.inst[1], C.c_int32), _ptr(self.inst[2], C.c_int32), _ptr(self.eig),
+            _ptr(self.wpost[0]), _ptr(self.wpost[1]), _ptr(self.wpost[2]),
+            C.c_int(self.degree), C.c_double(self.theta), C.c_double(self.delta), _ptr(x), _ptr(b), C.c_int(self.n_threads), C.c_int(reps))
+        if err:
+            raise RuntimeError("oracle_cpu_cheb_step failed (odd number of cells in a periodic direction?)")
+        return x

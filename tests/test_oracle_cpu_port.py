@@ -1,0 +1,39 @@
+"""The threaded C++ CPU restatement (oracle/asm_oracle_cpu.cc, used as cpu_baseline) agrees
+with the numpy oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import asm_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cpu_mod():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    import asm_oracle_cpu
+
+    return asm_oracle_cpu
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+@pytest.mark.parametrize("degree", [1, 3])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_cpu_port_matches_numpy_oracle(cpu_mod, periodic, degree, threads):
+    nc = (4, 6, 4)
+    extent = (1.0, 1.5, 0.5)
+    bc = orc.PERIODIC if periodic else orc.DIRICHLET
+    mesh = orc.Mesh(nc, 4, [bc] * 3, h=[extent[d] / nc[d] for d in range(3)])
+    op = orc.LaplaceOperator(mesh)
+    prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
+    cheb = orc.Chebyshev(op, prec, degree=degree, lambda_max=1.8)
+    rng = np.random.default_rng(4)
+    x0, b = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+    sm = cpu_mod.CpuSmoother(nc, periodic, extent, degree=degree, lambda_max=1.8, n_threads=threads)
+    assert sm.n_dofs == mesh.n_dofs
+    got = sm.step(x0, b)
+    ref = cheb.step(x0, b)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-12
