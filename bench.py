@@ -58,7 +58,7 @@ def cpu_baseline(args, pkg):
     if args.workload != "kershaw":
         import asm_oracle_cpu
 
-        threads = max(1, min(os.cpu_count() or 1, 64))
+        threads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
         nc = (40, 40, 40) if args.workload == "cart_dirichlet" else (48, 32, 32)
         sm = asm_oracle_cpu.CpuSmoother(nc, args.workload == "cart_periodic", degree=args.degree, lambda_max=1.7, n_threads=threads)
         b = np.ones(sm.n_dofs)
@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--what", default="cheb_step", choices=["cheb_step", "cheb_vmult"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (CPU share of one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
