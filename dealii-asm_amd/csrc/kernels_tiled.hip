@@ -5,21 +5,21 @@
 //     marches along z over a chunk of cell layers; per layer it computes 12 x 8
 //     cells (one halo column / row on the low sides, so that every owned DoF sees
 //     all the cells that contribute to it);
-//   * wave w handles cell row w of the tile: 12 cells x 5 lanes, lane (cell, k)
-//     holds one 5 x 5 plane of the cell's 5 x 5 x 5 patch tile in registers;
-//   * the two in-plane 1-D sweeps run on registers, the third direction is reached
+//   * wave w handles cell row w of the tile: 12 cells x 5 lanes, a lane holds one
+//     5 x 5 slice of the cell's 5 x 5 x 5 patch tile in registers;
+//   * two 1-D sweep directions run on registers, the third direction is reached
 //     by a 5-lane transpose through a small wave-private LDS buffer (no workgroup
 //     barrier involved);
-//   * the cells' output planes are summed into four LDS DoF planes (even cell rows,
-//     barrier, odd cell rows, so that the order of the additions is fixed), the
-//     z-neighbour's share travels from layer to layer through a wave-private LDS
-//     carry, and the owner thread of every DoF applies the fused vector update and
-//     stores it once, coalesced.
+//   * contributions to shared DoFs are merged where they are produced: in x by a
+//     5-lane shift inside the wave, in z through registers the lane keeps from one
+//     layer to the next, in y through a 20-double LDS slot per cell (one barrier per
+//     layer); the lane that then holds a DoF's final value applies the fused vector
+//     update and stores it once (16-byte stores, rows of 4 DoFs).
 // This replaces, for the headline configuration, the gather / apply_inverse /
 // scatter-add of ASPoissonPreconditioner::vmult_internal (include/matrix_free.h:
 // 1023-1062), the cell loop of LaplaceOperatorMatrixFree::vmult (include/operator.h:
 // 1367-1430) and the pre/post lambdas PreconditionChebyshev hands to both: dst needs
-// no zeroing, no atomics on HBM and no compress(add); results are bitwise reproducible.
+// no zeroing, no atomics and no compress(add); results are bitwise reproducible.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -42,17 +42,14 @@ namespace asmamd
     constexpr int OX  = WX - 1;   // owned cells per tile, x
     constexpr int OY  = TY - 1;   // owned cells per tile, y
     constexpr int NT  = TY * 64;  // threads
-    constexpr int PX  = P * WX + 1; // DoFs per tile row (49)
-    constexpr int PY  = P * TY + 1; // DoF rows per tile (33)
-    constexpr int NR  = 5;        // rows per epilogue thread: Jr = wave + 8 r
     constexpr int EIG = NE + N1;  // eigen data per 1-D instance
+    constexpr int YS  = P * N1;   // doubles per y-merge slot: planes 0..3 x columns 0..4
 
-    constexpr int LDS_OUT   = 4 * PY * PX;  // four DoF planes
-    constexpr int TBUF      = 64 * N1;          // one transpose buffer (all 64 lanes write, no predicate)
-    constexpr int LDS_T     = TY * 2 * TBUF;    // two per wave
-    constexpr int LDS_CARRY = TY * WX * NE; // top planes of the previous layer
-    constexpr int LDS_TAB   = 16 * EIG;     // eigen tables / reference matrices
-    constexpr int LDS_TOTAL = LDS_OUT + LDS_T + LDS_CARRY + LDS_TAB;
+    constexpr int TBUF      = 64 * N1;           // one transpose buffer (all 64 lanes write, no predicate)
+    constexpr int LDS_T     = TY * 2 * TBUF;     // two per wave
+    constexpr int LDS_Y     = 2 * TY * WX * YS;  // y-merge slots, double-buffered
+    constexpr int LDS_TAB   = 16 * EIG;          // eigen tables
+    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_TAB;
 
     struct Tiling
     {
@@ -82,23 +79,11 @@ namespace asmamd
       return g.wrap[d] || g.ext_lo[d] < 0; // periodic image or halo cell of the lower rank
     }
 
-    // is tile-relative DoF coordinate rel (logical I) written by this tile?
-    __device__ __forceinline__ bool
-    tile_owns(const DevGrid &g, const int d, const int rel, const int I, const int tile_cells)
-    {
-      if (I < 0 || I > g.own_hi[d] || rel < P)
-        return false;
-      return rel < P * tile_cells || I == g.nc[d] * P;
-    }
-
     // FWD: out[a] = sum_i q[i][a] in[i];  else out[i] = sum_a q[i][a] in[a]
     template <bool FWD, typename Q>
     __device__ __forceinline__ void
     line5(double &u0, double &u1, double &u2, double &u3, double &u4, const Q &q)
     {
-#if defined(ASM_ABLATE) && (ASM_ABLATE == 1 || ASM_ABLATE >= 4)
-      return; // diagnostic build: sweeps removed (results are wrong)
-#endif
       double o[N1];
 #pragma unroll
       for (int a = 0; a < N1; ++a)
@@ -155,18 +140,26 @@ namespace asmamd
     }
 
     // ---------------------------------------------------------------------------
-    // compute role of a lane
+    // role of a lane.  Two register layouts of a cell's 5 x 5 x 5 tile over its 5 lanes:
+    //   layout A: lane sub = z plane k, registers v[j*5 + i]
+    //   layout B: lane sub = y row   j, registers v[k*5 + i]
+    // transpose5 switches between them.  Results are merged and stored in layout B.
     // ---------------------------------------------------------------------------
     struct CellLane
     {
-      int  lane, w, cl, sub; // sub = plane (layout A) or row (layout B) within the cell
-      bool lane_ok;          // lanes 60..63 idle
+      int  lane, w, cl, sub;
+      bool lane_ok; // lanes 60..63 idle
       int  cx, cy;
       bool cell_xy;
-      // storage offset of the cell's DoF (i, j) = off0 + j stride_y + i, except that the last
+      // storage offset of the cell's DoF (i, j) = off0 + j sy + i, except that the last
       // column / row may wrap around a periodic seam: xw4 / yw4 hold that correction (0 otherwise)
-      int      off0, xw4, yw4;
+      int      off0, sy, xw4, yw4;
+      int      rowoff; // off0 + sub sy (+ yw4): the lane's row in layout B
       unsigned xd, yd; // Dirichlet masks of the cell's columns / rows
+      // ownership (layout B): the lane stores columns 0..3 (and 4 if own_c4) of its row
+      bool own_row, own_c4;
+      bool left_ok, below_ok; // the x / y neighbour cell whose last column / row ends in this cell is computed
+      int  shl5;              // ds_bpermute address of lane - 5
     };
 
     __device__ __forceinline__ void
@@ -180,15 +173,17 @@ namespace asmamd
       c.cx      = X0 + c.cl;
       c.cy      = Y0 + c.w;
       c.cell_xy = c.lane_ok && cell_computable(g, 0, c.cx) && cell_computable(g, 1, c.cy);
-      c.off0 = c.xw4 = c.yw4 = 0;
+      c.off0 = c.sy = c.xw4 = c.yw4 = c.rowoff = 0;
       c.xd = c.yd = 0u;
       if (c.cell_xy)
         {
           // every DoF of a computable cell exists; columns 0..3 / rows 0..3 are contiguous
           const int x0 = g.store_index_near(0, P * c.cx), y0 = g.store_index_near(1, P * c.cy);
-          c.off0       = (int)(y0 * g.stride[1]) + x0;
+          c.sy         = (int)g.stride[1];
+          c.off0       = y0 * c.sy + x0;
           c.xw4        = g.store_index_near(0, P * c.cx + P) - (x0 + P);
-          c.yw4        = (int)((g.store_index_near(1, P * c.cy + P) - (y0 + P)) * g.stride[1]);
+          c.yw4        = (g.store_index_near(1, P * c.cy + P) - (y0 + P)) * c.sy;
+          c.rowoff     = c.off0 + c.sub * c.sy + (c.sub == N1 - 1 ? c.yw4 : 0);
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             {
@@ -196,27 +191,37 @@ namespace asmamd
               c.yd |= (g.dirichlet(1, P * c.cy + i) ? 1u : 0u) << i;
             }
         }
+      // a cell is stored by the tile that holds it outside its halo row / column; the cell's
+      // DoFs (0..3)^3 belong to it, the block's last plane to the last cell
+      const bool owned_cell = c.cell_xy && c.cl >= 1 && c.w >= 1;
+      const bool last_col   = !g.wrap[0] && g.own_hi[0] == g.nc[0] * P && c.cx == g.nc[0] - 1;
+      const bool last_row   = !g.wrap[1] && g.own_hi[1] == g.nc[1] * P && c.cy == g.nc[1] - 1;
+      c.own_row             = owned_cell && (c.sub < N1 - 1 || last_row);
+      c.own_c4              = c.own_row && last_col;
+      c.left_ok             = c.cell_xy && c.cl >= 1 && cell_computable(g, 0, c.cx - 1);
+      c.below_ok            = c.cell_xy && c.w >= 1 && cell_computable(g, 1, c.cy - 1);
+      c.shl5                = (c.lane >= N1 ? c.lane - N1 : c.lane) << 2;
     }
 
-    // gather plane K of the lane's cell; MASK: constrained DoFs read as zero.
+    __device__ __forceinline__ long long
+    plane_offset(const DevGrid &g, const int K)
+    {
+      return g.store_index_near(2, K) * g.stride[2];
+    }
+
+    // layout A: plane K of the lane's cell, v[j*5 + i]; MASK: constrained DoFs read as zero.
     // Every DoF of a computable cell exists (the patch is the cell itself), so the 25
-    // loads need no predicate; lanes without a cell read offset 0 and are zeroed by the
-    // caller.  Dirichlet masking only touches lanes whose cell lies on the boundary.
+    // loads need no predicate; lanes without a cell read offset 0.  Dirichlet masking
+    // only touches lanes whose cell lies on the boundary.
     template <bool MASK>
     __device__ __forceinline__ void
     gather_plane(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int K, double (&v)[NE])
     {
-      const double *pl = src + (c.cell_xy ? g.store_index_near(2, K) * g.stride[2] : 0) + c.off0;
-#if defined(ASM_ABLATE) && ASM_ABLATE == 4
-      for (int e = 0; e < NE; ++e)
-        v[e] = 1.0 + e + K; // diagnostic build: no gather
-      return;
-#endif
-      const int sy = c.cell_xy ? (int)g.stride[1] : 0;
+      const double *pl = src + (c.cell_xy ? plane_offset(g, K) : 0) + c.off0;
 #pragma unroll
       for (int j = 0; j < N1; ++j)
         {
-          const double *row = pl + j * sy + (j == N1 - 1 ? c.yw4 : 0);
+          const double *row = pl + j * c.sy + (j == N1 - 1 ? c.yw4 : 0);
 #pragma unroll
           for (int i = 0; i < N1 - 1; ++i)
             v[j * 5 + i] = row[i];
@@ -237,15 +242,43 @@ namespace asmamd
         }
     }
 
+    // layout B: row sub of the planes P cz .. P cz + 4 of the lane's cell, v[k*5 + i]
+    template <bool MASK>
+    __device__ __forceinline__ void
+    gather_rows(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int cz, double (&v)[NE])
+    {
+#pragma unroll
+      for (int k = 0; k < N1; ++k)
+        {
+          const double *row = src + plane_offset(g, P * cz + k) + c.rowoff;
+#pragma unroll
+          for (int i = 0; i < N1 - 1; ++i)
+            v[k * 5 + i] = row[i];
+          v[k * 5 + N1 - 1] = row[N1 - 1 + c.xw4];
+        }
+      if (MASK)
+        {
+          const bool     yd = (c.yd >> c.sub) & 1u;
+          const unsigned zd = (g.dirichlet(2, P * cz) ? 1u : 0u) | (g.dirichlet(2, P * cz + P) ? 16u : 0u);
+          if (c.cell_xy && (yd || zd != 0u || c.xd != 0u))
+            {
+#pragma unroll
+              for (int k = 0; k < N1; ++k)
+#pragma unroll
+                for (int i = 0; i < N1; ++i)
+                  if (yd || (((c.xd >> i) | (zd >> k)) & 1u))
+                    v[k * 5 + i] = 0.;
+            }
+        }
+    }
+
     // 5-lane transpose: lane `sub` of a cell holds v[s*5 + f]; afterwards it holds
-    // v'[s*5 + f] = (value v[sub*5 + f] of the cell's lane s).  One fast index f per
-    // round through the wave-private buffer (2 x 300 doubles).
+    // v'[s*5 + f] = (value v[sub*5 + f] of the cell's lane s), i.e. the lane index and the
+    // slow register index change places (layout A <-> B).  One fast index f per round
+    // through the wave-private buffer (2 x 320 doubles).
     __device__ __forceinline__ void
     transpose5(double (&v)[NE], double *__restrict__ Tw, const CellLane &c)
     {
-#if defined(ASM_ABLATE) && (ASM_ABLATE == 3 || ASM_ABLATE == 1 || ASM_ABLATE >= 4)
-      return; // diagnostic build: transposes removed (results are wrong)
-#endif
       double n[NE];
       // lanes 60..63 hold no cell: they run along unpredicated (their cl = 12 slots exist)
 #pragma unroll
@@ -268,266 +301,165 @@ namespace asmamd
         v[e] = n[e];
     }
 
-    // ---------------------------------------------------------------------------
-    // epilogue role: thread (lane, wave) owns tile column Ir = lane (< 49) and rows
-    // Jr = wave + 8 r, r = 0..4, of every output plane
-    // ---------------------------------------------------------------------------
-    struct PlaneRole
+    // value of lane - 5 (the same row / plane of the x-neighbour cell)
+    __device__ __forceinline__ double
+    lane_shift5(const double x, const int addr)
     {
-      int       lane, wave;
-      int       J0, ny, wrap_y, lo_y;
-      long long stride_y;
-      unsigned  row_owned, row_dirichlet;
-      long long col_off;
-      bool      col_in, col_owned, col_dirichlet;
-    };
-
-    __device__ __forceinline__ void
-    role_setup(const DevGrid &g, const int I0, const int J0, PlaneRole &m)
-    {
-      m.lane     = threadIdx.x & 63;
-      m.wave     = threadIdx.x >> 6;
-      m.J0       = J0;
-      m.ny       = g.nc[1] * g.p;
-      m.wrap_y   = g.wrap[1];
-      m.lo_y     = g.ext_lo[1];
-      m.stride_y = g.stride[1];
-      m.row_owned = m.row_dirichlet = 0u;
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        {
-          const int  Jr = m.wave + TY * r, J = J0 + Jr;
-          const bool ow = Jr < PY && g.exists(1, J) && tile_owns(g, 1, Jr, J, TY);
-          m.row_owned |= (ow ? 1u : 0u) << r;
-          m.row_dirichlet |= ((ow && g.dirichlet(1, J)) ? 1u : 0u) << r;
-        }
-      const int I     = I0 + m.lane;
-      m.col_in        = m.lane < PX;
-      m.col_owned     = m.col_in && g.exists(0, I) && tile_owns(g, 0, m.lane, I, WX);
-      m.col_off       = m.col_owned ? g.store_index_near(0, I) * g.stride[0] : 0;
-      m.col_dirichlet = m.col_owned && g.dirichlet(0, I);
+      const unsigned long long u  = (unsigned long long)__double_as_longlong(x);
+      const unsigned           lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(u & 0xffffffffull));
+      const unsigned           hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(u >> 32));
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
 
-    __device__ __forceinline__ long long
-    row_offset(const PlaneRole &m, const int r)
-    {
-      int J = m.J0 + m.wave + TY * r;
-      if (m.wrap_y)
-        J += (J < 0) ? m.ny : ((J >= m.ny) ? -m.ny : 0);
-      else
-        J -= m.lo_y;
-      return J * m.stride_y;
-    }
+    // 16-byte accesses to 8-byte aligned rows
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    typedef dbl2   dbl2_u __attribute__((aligned(8)));
 
-    // operands of the fused update for the (up to) 20 DoFs a thread stores per layer;
-    // loaded before the accumulation barriers so that their latency is hidden
-    constexpr int NEP = (N1 - 1) * NR;
-    template <int MODE>
+    // ---------------------------------------------------------------------------
+    // merge + store (layout B): o[k*5 + i] holds the lane's row of the cell's output tile.
+    //   x: column 4 of the left cell is added to column 0 (5-lane shift inside the wave);
+    //   z: plane 4 stays in the lane's registers (`carry`) and is added to plane 0 of the next layer;
+    //   y: row 4 (lanes sub = 4) goes through a small LDS slot to the lanes sub = 0 of the wave
+    //      above, one workgroup barrier per layer, slots double-buffered by layer parity.
+    // After that every lane holds the final values of the DoFs it owns (columns 0..3 of its row,
+    // planes 0..3) and applies the fused vector update while storing them: each DoF is
+    // written once, no atomics, fixed summation order.
+    // ---------------------------------------------------------------------------
+    template <int MODE, int NPL>
     struct EpilogueOperands
     {
       static constexpr bool need_a = (MODE == OP_RESIDUAL || MODE == PC_STEP1 || MODE == PC_UPDATE);
       static constexpr bool need_b = (MODE == PC_UPDATE);
-      double a[need_a ? NEP : 1];
-      double b[need_b ? NEP : 1];
+      double a[need_a ? NPL * P : 1];
+      double b[need_b ? NPL * P : 1];
     };
 
-    __device__ __forceinline__ long long
-    dof_offset(const DevGrid &g, const PlaneRole &m, const int K, const int r)
-    {
-      return g.store_index_near(2, K) * g.stride[2] + m.col_off + row_offset(m, r);
-    }
-
-    template <int MODE>
+    // operands of the fused update of planes K0 .. K0 + NPL - 1: issued early, used after the merge
+    template <int MODE, int NPL>
     __device__ __forceinline__ void
-    epilogue_prefetch(const DevGrid &g, const PlaneRole &m, const TiledArgs &a, const int K0, const int nplanes,
-                      EpilogueOperands<MODE> &ops)
+    epilogue_prefetch(const DevGrid &g, const CellLane &c, const TiledArgs &a, const int K0, EpilogueOperands<MODE, NPL> &ops)
     {
-      if (!EpilogueOperands<MODE>::need_a)
+      if (!EpilogueOperands<MODE, NPL>::need_a)
         return;
-#if defined(ASM_ABLATE) && (ASM_ABLATE == 6 || ASM_ABLATE == 7)
-      for (int e = 0; e < NEP; ++e)
-        ops.a[e] = 1.0 + e; // diagnostic build: no operand loads
-      return;
-#endif
       const double *pa = (MODE == OP_RESIDUAL) ? a.b : a.x;
 #pragma unroll
-      for (int kk = 0; kk < N1 - 1; ++kk)
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-          {
-            const bool      own = kk < nplanes && m.col_owned && ((m.row_owned >> r) & 1u);
-            const long long off = own ? dof_offset(g, m, K0 + kk, r) : 0;
-            ops.a[kk * NR + r]  = pa[off];
-            if (EpilogueOperands<MODE>::need_b)
-              ops.b[kk * NR + r] = a.x_old[off];
-          }
-    }
-
-    // store plane kk of S_out as DoF plane K (fused update of the mode) and clear it
-    template <int MODE>
-    __device__ __forceinline__ void
-    plane_epilogue(const DevGrid &g, const PlaneRole &m, const TiledArgs &a, double *__restrict__ S_out, const int kk,
-                   const int K, const EpilogueOperands<MODE> &ops)
-    {
-      if (!m.col_in)
-        return;
-      const bool dk = g.dirichlet(2, K) || m.col_dirichlet;
-      double *   pl = S_out + kk * (PY * PX) + m.lane;
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
+      for (int k = 0; k < NPL; ++k)
         {
-          const int Jr = m.wave + TY * r;
-          if (Jr < PY)
+          const long long off = plane_offset(g, K0 + k) + c.rowoff;
+#pragma unroll
+          for (int i = 0; i < P; ++i)
             {
-              double t    = pl[Jr * PX];
-              pl[Jr * PX] = 0.;
-#if defined(ASM_ABLATE) && ASM_ABLATE == 6
-              if (t != 1.2345e300)
-                continue; // diagnostic build: no stores
-#endif
-              if (m.col_owned && ((m.row_owned >> r) & 1u))
-                {
-                  const long long off         = dof_offset(g, m, K, r);
-                  const bool      constrained = dk || ((m.row_dirichlet >> r) & 1u);
-                  const double    oa = ops.a[EpilogueOperands<MODE>::need_a ? kk * NR + r : 0];
-                  const double    ob = ops.b[EpilogueOperands<MODE>::need_b ? kk * NR + r : 0];
-                  if (MODE == OP_PLAIN || MODE == PC_PLAIN)
-                    a.dst[off] = constrained ? 0. : t;
-                  else if (MODE == OP_RESIDUAL)
-                    // (A x)_c = x_c on constrained DoFs (matrix_free_internal.h:247-255)
-                    a.dst[off] = oa - (constrained ? a.src[off] : t);
-                  else
-                    {
-                      if (constrained)
-                        t = a.src[off]; // unit rows of P^-1 on constrained DoFs
-                      if (MODE == PC_FIRST)
-                        a.dst[off] = a.f2 * t;
-                      else if (MODE == PC_STEP1)
-                        a.dst[off] = a.f1 * oa + a.f2 * t;
-                      else
-                        a.dst[off] = oa + a.f1 * (oa - ob) + a.f2 * t;
-                    }
-                }
+              ops.a[k * P + i] = pa[off + i];
+              if (EpilogueOperands<MODE, NPL>::need_b)
+                ops.b[k * P + i] = a.x_old[off + i];
             }
         }
     }
 
-    // add the cell plane o (lane (cell, k), k < 4) into output plane k
-    __device__ __forceinline__ void
-    accumulate_plane(double *__restrict__ S_out, const CellLane &c, const int kk, const double (&o)[NE])
-    {
-      double *pl = S_out + kk * (PY * PX) + (P * c.w) * PX + P * c.cl;
-#if defined(ASM_ABLATE) && ASM_ABLATE == 5
-      if (o[3] == 1.2345e300)
-        pl[0] = o[0]; // diagnostic build: no accumulation
-      return;
-#endif
-#pragma unroll
-      for (int j = 0; j < N1; ++j)
-#pragma unroll
-        for (int i = 0; i < N1; ++i)
-          __hip_atomic_fetch_add(pl + j * PX + i, o[j * 5 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-
-    // carry exchange + accumulation of one layer's cell planes
-    // On return o holds the gathered src plane of the NEXT layer (k_next >= 0): the loads are
-    // issued as soon as o is dead, so they travel under the barriers and the store epilogue.
-    template <int MODE, bool MASK>
-    __device__ __forceinline__ void
-    exchange_and_store(const DevGrid &g, const PlaneRole &m, const CellLane &c, const TiledArgs &a, double *__restrict__ S_out,
-                       double *__restrict__ S_carry, double (&o)[NE], const bool active, const bool halo_layer, const int cz,
-                       const int k_next)
-    {
-      EpilogueOperands<MODE> ops;
-      if (!halo_layer)
-        epilogue_prefetch<MODE>(g, m, a, P * cz, N1 - 1, ops);
-      double *cw = S_carry + (c.w * WX + c.cl) * NE;
-      // plane 0 receives the top plane of the layer below (same cell column)
-      if (c.lane_ok && c.sub == 0)
-        {
-#pragma unroll
-          for (int e = 0; e < NE; ++e)
-            o[e] += cw[e];
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (c.lane_ok && c.sub == N1 - 1)
-        {
-#pragma unroll
-          for (int e = 0; e < NE; ++e)
-            cw[e] = active ? o[e] : 0.;
-        }
-      if (halo_layer)
-        {
-          // wave-uniform: the halo layer only feeds the carry
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (k_next >= 0)
-            gather_plane<MASK>(g, c, a.src, k_next, o);
-          return;
-        }
-#if defined(ASM_ABLATE) && ASM_ABLATE == 2
-      // diagnostic build: no accumulation, no epilogue (results are wrong)
-      if (active && o[0] == 1.2345e300)
-        a.dst[0] = o[1];
-      if (k_next >= 0)
-        gather_plane<MASK>(g, c, a.src, k_next, o);
-      return;
-#endif
-      // even cell rows, then odd cell rows: rows of equal parity share no DoF row
-      if ((c.w & 1) == 0)
-        {
-          if (active && c.sub < N1 - 1)
-            accumulate_plane(S_out, c, c.sub, o);
-          if (k_next >= 0)
-            gather_plane<MASK>(g, c, a.src, k_next, o);
-        }
-      __syncthreads();
-      if ((c.w & 1) == 1)
-        {
-          if (active && c.sub < N1 - 1)
-            accumulate_plane(S_out, c, c.sub, o);
-          if (k_next >= 0)
-            gather_plane<MASK>(g, c, a.src, k_next, o);
-        }
-      __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < N1 - 1; ++kk)
-        plane_epilogue<MODE>(g, m, a, S_out, kk, P * cz + kk, ops);
-      __syncthreads();
-    }
-
-    // top plane of the block (physical boundary): only the last layer contributes
     template <int MODE>
-    __device__ __forceinline__ void
-    store_top_plane(const DevGrid &g, const PlaneRole &m, const CellLane &c, const TiledArgs &a, double *__restrict__ S_out,
-                    double *__restrict__ S_carry)
+    __device__ __forceinline__ double
+    fused_update(const TiledArgs &a, const double t, const double oa, const double ob)
     {
-      EpilogueOperands<MODE> ops;
-      epilogue_prefetch<MODE>(g, m, a, P * g.nc[2], 1, ops);
-      double        o[NE];
-      const double *cw = S_carry + (c.w * WX + c.cl) * NE;
-      const bool    on = c.lane_ok && c.sub == 0;
-      if (on)
-        {
-#pragma unroll
-          for (int e = 0; e < NE; ++e)
-            o[e] = cw[e];
-        }
-      if ((c.w & 1) == 0 && on)
-        accumulate_plane(S_out, c, 0, o);
-      __syncthreads();
-      if ((c.w & 1) == 1 && on)
-        accumulate_plane(S_out, c, 0, o);
-      __syncthreads();
-      plane_epilogue<MODE>(g, m, a, S_out, 0, P * g.nc[2], ops);
+      if (MODE == OP_PLAIN || MODE == PC_PLAIN)
+        return t;
+      if (MODE == OP_RESIDUAL)
+        return oa - t;
+      if (MODE == PC_FIRST)
+        return a.f2 * t;
+      if (MODE == PC_STEP1)
+        return a.f1 * oa + a.f2 * t;
+      return oa + a.f1 * (oa - ob) + a.f2 * t;
     }
 
+    // x- and z-merge; on return o holds the x/z-complete rows, carry the top plane
     __device__ __forceinline__ void
-    lds_clear(double *__restrict__ S_out, double *__restrict__ S_carry)
+    merge_xz(const CellLane &c, double (&o)[NE], double (&carry)[N1])
     {
-      for (int e = threadIdx.x; e < LDS_OUT; e += NT)
-        S_out[e] = 0.;
-      for (int e = threadIdx.x; e < LDS_CARRY; e += NT)
-        S_carry[e] = 0.;
+      double r[N1];
+#pragma unroll
+      for (int k = 0; k < N1; ++k)
+        r[k] = lane_shift5(o[k * 5 + N1 - 1], c.shl5);
+      if (c.left_ok)
+        {
+#pragma unroll
+          for (int k = 0; k < N1; ++k)
+            o[k * 5] += r[k];
+        }
+#pragma unroll
+      for (int i = 0; i < N1; ++i)
+        {
+          o[i] += carry[i];
+          carry[i] = o[(N1 - 1) * 5 + i];
+        }
+    }
+
+    template <int MODE, int NPL>
+    __device__ __forceinline__ void
+    merge_y_and_store(const DevGrid &g, const CellLane &c, const TiledArgs &a, double *__restrict__ Sy, double (&o)[NE],
+                      const int K0, const EpilogueOperands<MODE, NPL> &ops)
+    {
+      // ---- y: row 4 -> row 0 of the cell above
+      if (c.cell_xy && c.sub == N1 - 1)
+        {
+          double *slot = Sy + (c.w * WX + c.cl) * YS;
+#pragma unroll
+          for (int k = 0; k < NPL; ++k)
+#pragma unroll
+            for (int i = 0; i < N1; ++i)
+              slot[k * 5 + i] = o[k * 5 + i];
+        }
+      __syncthreads();
+      if (c.below_ok && c.sub == 0)
+        {
+          const double *slot = Sy + ((c.w - 1) * WX + c.cl) * YS;
+#pragma unroll
+          for (int k = 0; k < NPL; ++k)
+#pragma unroll
+            for (int i = 0; i < N1; ++i)
+              o[k * 5 + i] += slot[k * 5 + i];
+        }
+      // ---- fused update + store
+      if (c.own_row)
+        {
+          const bool yd = (c.yd >> c.sub) & 1u;
+#pragma unroll
+          for (int k = 0; k < NPL; ++k)
+            {
+              const long long off = plane_offset(g, K0 + k) + c.rowoff;
+              const unsigned  cm  = (yd || g.dirichlet(2, K0 + k)) ? 0x1fu : c.xd;
+              double          t[N1];
+#pragma unroll
+              for (int i = 0; i < N1; ++i)
+                t[i] = o[k * 5 + i];
+              if (cm != 0u)
+                {
+                  // constrained DoFs: zero (plain product) or the identity row (fused modes:
+                  // (A x)_c = x_c, matrix_free_internal.h:247-255; unit rows of P^-1)
+#pragma unroll
+                  for (int i = 0; i < N1; ++i)
+                    if ((cm >> i) & 1u)
+                      t[i] = (MODE == OP_PLAIN || MODE == PC_PLAIN) ? 0. : a.src[off + i];
+                }
+              constexpr bool na = EpilogueOperands<MODE, NPL>::need_a, nb = EpilogueOperands<MODE, NPL>::need_b;
+              double         rr[P];
+#pragma unroll
+              for (int i = 0; i < P; ++i)
+                rr[i] = fused_update<MODE>(a, t[i], ops.a[na ? k * P + i : 0], ops.b[nb ? k * P + i : 0]);
+              dbl2 lo, hi;
+              lo.x = rr[0];
+              lo.y = rr[1];
+              hi.x = rr[2];
+              hi.y = rr[3];
+              *(dbl2_u *)(a.dst + off)     = lo;
+              *(dbl2_u *)(a.dst + off + 2) = hi;
+              if (c.own_c4)
+                {
+                  const double oa   = na ? ((MODE == OP_RESIDUAL) ? a.b : a.x)[off + P] : 0.;
+                  const double ob   = nb ? a.x_old[off + P] : 0.;
+                  a.dst[off + P]    = fused_update<MODE>(a, t[P], oa, ob);
+                }
+            }
+        }
     }
 
     // ---------------------------------------------------------------------------
@@ -538,33 +470,33 @@ namespace asmamd
     fdm_tiled_kernel(const DevGrid g, const DevFdm f, const TiledArgs a, const Tiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
-      double *S_out   = lds;
-      double *S_T     = S_out + LDS_OUT;
-      double *S_carry = S_T + LDS_T;
-      double *S_tab   = S_carry + LDS_CARRY;
+      double *S_T   = lds;
+      double *S_Y   = S_T + LDS_T;
+      double *S_tab = S_Y + LDS_Y;
 
       const int b  = xcd_remap(blockIdx.x, gridDim.x);
       const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
       const int X0 = tx * OX - 1, Y0 = ty * OY - 1; // tile cell (0,0)
 
-      PlaneRole m;
-      role_setup(g, P * X0, P * Y0, m);
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
       double *Tw = S_T + c.w * (2 * TBUF);
 
       // eigen tables of tensor-product meshes live in LDS (the launcher checks n_inst <= 16)
       if (TENSOR)
-        for (int e = threadIdx.x; e < f.n_inst * EIG; e += NT)
-          S_tab[e] = f.eig[e];
-      lds_clear(S_out, S_carry);
-      __syncthreads();
+        {
+          for (int e = threadIdx.x; e < f.n_inst * EIG; e += NT)
+            S_tab[e] = f.eig[e];
+          __syncthreads();
+        }
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
 
-      double v[NE]; // the lane's plane; reloaded with the next layer inside exchange_and_store
-      gather_plane<false>(g, c, a.src, P * z_first + c.sub, v);
+      double v[NE]; // the lane's rows (layout B); reloaded with the next layer after the store
+      double carry[N1] = {0., 0., 0., 0., 0.};
+      int    par       = 0;
+      gather_rows<false>(g, c, a.src, z_first, v);
       const int cxs = c.cell_xy ? c.cx : 0, cys = c.cell_xy ? c.cy : 0; // table rows that exist
       for (int cz = z_first; cz < Ze; ++cz)
         {
@@ -606,18 +538,18 @@ namespace asmamd
 
           double q[NE];
           // Lanes without a cell run along unpredicated on harmless data (table row 0, src
-          // offset 0); nothing they compute is ever accumulated or carried.
-          // ---- layout A: lane = (cell, z plane k); x and y forward sweeps -----------
+          // offset 0); nothing they compute is ever merged or stored.
+          // ---- layout B: lane = (cell, y row j), v[k*5 + i]; x and z forward sweeps -------
           if (HAS_PRE)
             {
-              const double wz = f.w_pre[2][(cz + 1) * N1 + c.sub];
+              const double wy = f.w_pre[1][(cys + 1) * N1 + c.sub];
 #pragma unroll
-              for (int j = 0; j < N1; ++j)
+              for (int k = 0; k < N1; ++k)
                 {
-                  const double wyz = f.w_pre[1][(cys + 1) * N1 + j] * wz;
+                  const double wyz = f.w_pre[2][(cz + 1) * N1 + k] * wy;
 #pragma unroll
                   for (int i = 0; i < N1; ++i)
-                    v[j * 5 + i] *= f.w_pre[0][(cxs + 1) * N1 + i] * wyz;
+                    v[k * 5 + i] *= f.w_pre[0][(cxs + 1) * N1 + i] * wyz;
                 }
             }
           if (x_uniform)
@@ -628,57 +560,59 @@ namespace asmamd
               sweep_fast<true>(v, q);
             }
           if (TENSOR)
-            sweep_slow<true>(v, Uy);
-          else
-            {
-              LOADQ(q, ey);
-              sweep_slow<true>(v, q);
-            }
-          // ---- layout B: lane = (cell, y index b), v[c*5 + a]; z sweeps + scaling ----
-          transpose5(v, Tw, c);
-          if (TENSOR)
             sweep_slow<true>(v, Uz);
           else
             {
               LOADQ(q, ez);
               sweep_slow<true>(v, q);
             }
+          // ---- layout A: lane = (cell, z index c), v[b*5 + a]; y sweeps + scaling ---------
+          transpose5(v, Tw, c);
+          if (TENSOR)
+            sweep_slow<true>(v, Uy);
+          else
+            {
+              LOADQ(q, ey);
+              sweep_slow<true>(v, q);
+            }
           if (f.inv_table != nullptr)
             {
-              const double *inv = f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) + c.sub * N1;
+              // table [iz][iy][ix][c][b][a]
+              const double *inv = f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) + c.sub * NE;
 #pragma unroll
-              for (int cc = 0; cc < N1; ++cc)
-#pragma unroll
-                for (int aa = 0; aa < N1; ++aa)
-                  v[cc * 5 + aa] *= inv[cc * NE + aa];
+              for (int e = 0; e < NE; ++e)
+                v[e] *= inv[e];
             }
           else
             {
-              const double lyb = TENSOR ? eyl[NE + c.sub] : eyg[NE + c.sub];
+              const double lzc = TENSOR ? ezl[NE + c.sub] : ezg[NE + c.sub];
 #pragma unroll
-              for (int cc = 0; cc < N1; ++cc)
+              for (int bb = 0; bb < N1; ++bb)
 #pragma unroll
                 for (int aa = 0; aa < N1; ++aa)
                   {
                     // reciprocal with two Newton steps (full double precision)
-                    const double sm = (TENSOR ? exl[NE + aa] : exg[NE + aa]) + (lyb + (TENSOR ? ezl[NE + cc] : ezg[NE + cc]));
+                    const double sm = (TENSOR ? exl[NE + aa] : exg[NE + aa]) + ((TENSOR ? eyl[NE + bb] : eyg[NE + bb]) + lzc);
                     double       r  = __builtin_amdgcn_rcp(sm);
                     r               = fma(fma(-sm, r, 1.0), r, r);
                     r               = fma(fma(-sm, r, 1.0), r, r);
-                    v[cc * 5 + aa] *= r;
+                    v[bb * 5 + aa] *= r;
                   }
             }
           if (TENSOR)
-            sweep_slow<false>(v, Uz);
-          else
-            sweep_slow<false>(v, q);
-          // ---- back to layout A; y and x backward sweeps, post weights ---------------
-          transpose5(v, Tw, c);
-          if (TENSOR)
             sweep_slow<false>(v, Uy);
           else
+            sweep_slow<false>(v, q);
+          // ---- back to layout B; z and x backward sweeps, post weights --------------------
+          transpose5(v, Tw, c);
+          EpilogueOperands<MODE, P> ops;
+          if (cz >= Zb)
+            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
+          if (TENSOR)
+            sweep_slow<false>(v, Uz);
+          else
             {
-              LOADQ(q, ey);
+              LOADQ(q, ez);
               sweep_slow<false>(v, q);
             }
           if (x_uniform)
@@ -690,22 +624,36 @@ namespace asmamd
             }
           if (HAS_POST)
             {
-              const double wz = f.w_post[2][(cz + 1) * N1 + c.sub];
+              const double wy = f.w_post[1][(cys + 1) * N1 + c.sub];
 #pragma unroll
-              for (int j = 0; j < N1; ++j)
+              for (int k = 0; k < N1; ++k)
                 {
-                  const double wyz = f.w_post[1][(cys + 1) * N1 + j] * wz;
+                  const double wyz = f.w_post[2][(cz + 1) * N1 + k] * wy;
 #pragma unroll
                   for (int i = 0; i < N1; ++i)
-                    v[j * 5 + i] *= f.w_post[0][(cxs + 1) * N1 + i] * wyz;
+                    v[k * 5 + i] *= f.w_post[0][(cxs + 1) * N1 + i] * wyz;
                 }
             }
-          exchange_and_store<MODE, false>(g, m, c, a, S_out, S_carry, v, active, cz < Zb, cz,
-                                          cz + 1 < Ze ? P * (cz + 1) + c.sub : -1);
+          merge_xz(c, v, carry);
+          if (cz >= Zb)
+            {
+              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops);
+              par ^= 1;
+            }
+          if (cz + 1 < Ze)
+            gather_rows<false>(g, c, a.src, cz + 1, v);
         }
 #undef LOADQ
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
-        store_top_plane<MODE>(g, m, c, a, S_out, S_carry);
+        {
+          // top plane of the block (physical boundary): what the last layer left in the carry
+          EpilogueOperands<MODE, 1> ops;
+          epilogue_prefetch<MODE, 1>(g, c, a, P * g.nc[2], ops);
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            v[i] = carry[i];
+          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops);
+        }
     }
 
     // ---------------------------------------------------------------------------
@@ -720,26 +668,19 @@ namespace asmamd
     laplace_cart_tiled_kernel(const DevGrid g, const DevOp op, const TiledArgs a, const Tiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
-      double *S_out   = lds;
-      double *S_T     = S_out + LDS_OUT;
-      double *S_carry = S_T + LDS_T;
-      double *S_tab   = S_carry + LDS_CARRY;
+      double *S_T = lds;
+      double *S_Y = S_T + LDS_T;
 
       const int b  = xcd_remap(blockIdx.x, gridDim.x);
       const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
       const int X0 = tx * OX - 1, Y0 = ty * OY - 1;
 
-      PlaneRole m;
-      role_setup(g, P * X0, P * Y0, m);
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
       double *Tw = S_T + c.w * (2 * TBUF);
 
       // reference matrices (row-major [i][j], symmetric): wave-uniform scalar operands
       const UniformMatrix Mm(op.M_ref), Km(op.K_ref);
-      (void)S_tab;
-      lds_clear(S_out, S_carry);
-      __syncthreads();
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
@@ -750,14 +691,15 @@ namespace asmamd
           hy = op.h[1][c.cy + 1];
         }
 
-      double u[NE]; // the lane's plane; reloaded with the next layer inside exchange_and_store
+      double u[NE]; // layout A on entry of a layer, layout B at its end
+      double carry[N1] = {0., 0., 0., 0., 0.};
+      int    par       = 0;
       gather_plane<true>(g, c, a.src, P * z_first + c.sub, u);
       for (int cz = z_first; cz < Ze; ++cz)
         {
-          const bool   active = c.cell_xy;
-          const double hz     = op.h[2][cz + 1];
+          const double hz = op.h[2][cz + 1];
           double       t2[NE];
-          // lanes without a cell run along unpredicated; nothing of theirs is accumulated or carried
+          // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
           // ---- layout A: x and y sweeps ------------------------------------------------
 #pragma unroll
           for (int e = 0; e < NE; ++e)
@@ -787,17 +729,32 @@ namespace asmamd
           // ---- layout B: z sweeps ------------------------------------------------------
           transpose5(t2, Tw, c);
           transpose5(u, Tw, c);
+          EpilogueOperands<MODE, P> ops;
+          if (cz >= Zb)
+            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
           sweep_slow<true>(u, Km);  // Kz (My Mx u)
           sweep_slow<true>(t2, Mm); // Mz (...)
 #pragma unroll
           for (int e = 0; e < NE; ++e)
             u[e] += t2[e];
-          transpose5(u, Tw, c);
-          exchange_and_store<MODE, true>(g, m, c, a, S_out, S_carry, u, active, cz < Zb, cz,
-                                         cz + 1 < Ze ? P * (cz + 1) + c.sub : -1);
+          merge_xz(c, u, carry);
+          if (cz >= Zb)
+            {
+              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops);
+              par ^= 1;
+            }
+          if (cz + 1 < Ze)
+            gather_plane<true>(g, c, a.src, P * (cz + 1) + c.sub, u);
         }
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
-        store_top_plane<MODE>(g, m, c, a, S_out, S_carry);
+        {
+          EpilogueOperands<MODE, 1> ops;
+          epilogue_prefetch<MODE, 1>(g, c, a, P * g.nc[2], ops);
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            u[i] = carry[i];
+          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops);
+        }
     }
 
     Tiling
