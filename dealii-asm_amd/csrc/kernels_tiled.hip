@@ -21,6 +21,7 @@
 // 1367-1430) and the pre/post lambdas PreconditionChebyshev hands to both: dst needs
 // no zeroing, no atomics and no compress(add); results are bitwise reproducible.
 #include "kernels.h"
+#include "numerics.h"
 
 #include <hip/hip_runtime.h>
 
@@ -129,6 +130,27 @@ namespace asmamd
         : p((const __attribute__((address_space(4))) double *)q)
       {}
       __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
+      // the same matrix behind a pointer the compiler cannot trace: its loads are issued where the
+      // copy is made instead of once before the layer loop (three resident matrices do not fit into
+      // the scalar registers and would be spilled to vector lanes)
+      __device__ __forceinline__ UniformMatrix fresh() const
+      {
+        UniformMatrix r(*this);
+        asm volatile("" : "+s"(r.p));
+        return r;
+      }
+    };
+
+    // the same for a matrix that is symmetric and invariant under (i, j) -> (4-i, 4-j), like the
+    // reference mass and stiffness matrices (numerics.h makes that hold bitwise): 9 distinct
+    // entries, so two such matrices stay resident in scalar registers
+    struct UniformSymMatrix
+    {
+      const __attribute__((address_space(4))) double *p;
+      __device__ __forceinline__ explicit UniformSymMatrix(const double *q)
+        : p((const __attribute__((address_space(4))) double *)q)
+      {}
+      __device__ __forceinline__ double operator[](const int e) const { return p[symmetric_entry(e / N1, e % N1, N1)]; }
     };
 
     __device__ __forceinline__ void
@@ -553,14 +575,14 @@ namespace asmamd
                 }
             }
           if (x_uniform)
-            sweep_fast<true>(v, Ux);
+            sweep_fast<true>(v, Ux.fresh());
           else
             {
               LOADQ(q, ex);
               sweep_fast<true>(v, q);
             }
           if (TENSOR)
-            sweep_slow<true>(v, Uz);
+            sweep_slow<true>(v, Uz.fresh());
           else
             {
               LOADQ(q, ez);
@@ -569,7 +591,7 @@ namespace asmamd
           // ---- layout A: lane = (cell, z index c), v[b*5 + a]; y sweeps + scaling ---------
           transpose5(v, Tw, c);
           if (TENSOR)
-            sweep_slow<true>(v, Uy);
+            sweep_slow<true>(v, Uy.fresh());
           else
             {
               LOADQ(q, ey);
@@ -600,7 +622,7 @@ namespace asmamd
                   }
             }
           if (TENSOR)
-            sweep_slow<false>(v, Uy);
+            sweep_slow<false>(v, Uy.fresh());
           else
             sweep_slow<false>(v, q);
           // ---- back to layout B; z and x backward sweeps, post weights --------------------
@@ -609,14 +631,14 @@ namespace asmamd
           if (cz >= Zb)
             epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
           if (TENSOR)
-            sweep_slow<false>(v, Uz);
+            sweep_slow<false>(v, Uz.fresh());
           else
             {
               LOADQ(q, ez);
               sweep_slow<false>(v, q);
             }
           if (x_uniform)
-            sweep_fast<false>(v, Ux);
+            sweep_fast<false>(v, Ux.fresh());
           else
             {
               LOADQ(q, ex);
@@ -680,7 +702,7 @@ namespace asmamd
       double *Tw = S_T + c.w * (2 * TBUF);
 
       // reference matrices (row-major [i][j], symmetric): wave-uniform scalar operands
-      const UniformMatrix Mm(op.M_ref), Km(op.K_ref);
+      const UniformSymMatrix Mm(op.M_ref), Km(op.K_ref);
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;

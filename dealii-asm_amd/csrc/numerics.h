@@ -137,6 +137,16 @@ namespace asmamd
         }
   }
 
+  // representative (smallest row-major index) of entry (i, j) of an n x n matrix that is
+  // symmetric and invariant under (i, j) -> (n-1-i, n-1-j)
+  constexpr int
+  symmetric_entry(const int i, const int j, const int n)
+  {
+    const int a = i * n + j, b = j * n + i, c = (n - 1 - i) * n + (n - 1 - j), d = (n - 1 - j) * n + (n - 1 - i);
+    const int ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+  }
+
   struct Basis1D
   {
     int                 p, n1;
@@ -169,6 +179,16 @@ namespace asmamd
               }
             M_ref[i * n1 + j] = (double)m;
             K_ref[i * n1 + j] = (double)k;
+          }
+      // The matrices are symmetric and, the nodes being symmetric about 1/2, invariant under
+      // (i, j) -> (p - i, p - j).  Make both hold bitwise, so that kernels may keep the 9 (p = 4)
+      // distinct entries only.
+      for (int i = 0; i < n1; ++i)
+        for (int j = 0; j < n1; ++j)
+          {
+            const int e = symmetric_entry(i, j, n1);
+            M_ref[i * n1 + j] = M_ref[e];
+            K_ref[i * n1 + j] = K_ref[e];
           }
     }
   };
