@@ -21,7 +21,7 @@
 #ifdef ASM_STAMP
 namespace asmamd
 {
-  void tiled_debug_stamps(unsigned long long out[16], bool reset);
+  void tiled_debug_stamps(unsigned long long out[32], bool reset);
 }
 #endif
 
@@ -971,7 +971,7 @@ asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms)
 #ifdef ASM_STAMP
 // diagnostic builds only (not declared in the public header)
 int
-asm_debug_stamps(asm_ctx *ctx, unsigned long long out[16], int reset)
+asm_debug_stamps(asm_ctx *ctx, unsigned long long out[32], int reset)
 {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   asmamd::tiled_debug_stamps(out, reset != 0);

@@ -32,6 +32,9 @@ namespace asmamd
   {
     return true;
   }
+#ifdef ASM_STAMP
+  void tiled_debug_stamps(unsigned long long out[32], bool reset);
+#endif
 
   namespace
   {
@@ -39,18 +42,75 @@ namespace asmamd
     constexpr int N1  = 5;
     constexpr int NE  = 25;       // values per cell plane
     constexpr int WX  = 12;       // cells per wave (x)
-    constexpr int TY  = 8;        // cell rows per tile = waves per workgroup
+#ifndef ASM_TY
+#  define ASM_TY 8
+#endif
+    constexpr int TY  = ASM_TY;   // cell rows per tile = waves per workgroup
     constexpr int OX  = WX - 1;   // owned cells per tile, x
     constexpr int OY  = TY - 1;   // owned cells per tile, y
     constexpr int NT  = TY * 64;  // threads
     constexpr int EIG = NE + N1;  // eigen data per 1-D instance
+    constexpr int PX_DOFS = P * WX + 1; // DoFs per tile row (49)
     constexpr int YS  = P * N1;   // doubles per y-merge slot: planes 0..3 x columns 0..4
 
     constexpr int TBUF      = 64 * N1;           // one transpose buffer (all 64 lanes write, no predicate)
     constexpr int LDS_T     = TY * 2 * TBUF;     // two per wave
     constexpr int LDS_Y     = 2 * TY * WX * YS;  // y-merge slots, double-buffered
     constexpr int LDS_TAB   = 16 * EIG;          // eigen tables
-    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_TAB;
+    // staged source rows of one wave and layer: 25 rows (5 planes x 5 DoF rows) of 25 16-byte chunks
+    constexpr int GCH       = (PX_DOFS + 1) / 2; // chunks per row
+    constexpr int GROW      = 2 * GCH;           // doubles per staged row (49 DoFs + 1)
+    constexpr int GN        = (NE * GCH + 63) / 64; // wave instructions per layer (10)
+    constexpr int GBUF      = GN * 128;          // doubles per wave
+    constexpr int LDS_G     = TY * GBUF;
+    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_G + LDS_TAB;
+
+#ifdef ASM_STAMP
+    // diagnostic build: cycles (s_memtime) an interior wave spends between the STAMP marks
+    __device__ unsigned long long g_stamps[32];
+    struct StampCtx
+    {
+      bool               on;
+      unsigned long long t, acc[16];
+    };
+#  define STAMP_DECL(base)                                                                  \
+    StampCtx stamp_ctx;                                                                     \
+    stamp_ctx.on = (blockIdx.x == gridDim.x / 2 + 3) && ((threadIdx.x >> 6) == 3);          \
+    stamp_ctx.t  = __builtin_amdgcn_s_memtime();                                            \
+    for (int i = 0; i < 16; ++i)                                                            \
+      stamp_ctx.acc[i] = 0;                                                                 \
+    constexpr int stamp_base = base;
+#  define STAMP(i)                                                        \
+    do                                                                    \
+      {                                                                   \
+        if (stamp_ctx.on)                                                 \
+          {                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
+            const unsigned long long t = __builtin_amdgcn_s_memtime();    \
+            stamp_ctx.acc[i] += t - stamp_ctx.t;                          \
+            stamp_ctx.t = t;                                              \
+          }                                                               \
+      }                                                                   \
+    while (0)
+#  define STAMP_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#  define STAMP_FLUSH()                                                          \
+    do                                                                           \
+      {                                                                          \
+        if (stamp_ctx.on && (threadIdx.x & 63) == 0)                             \
+          for (int i = 0; i < 16; ++i)                                           \
+            atomicAdd(&g_stamps[stamp_base + i], stamp_ctx.acc[i]);              \
+      }                                                                          \
+    while (0)
+#  define STAMP_PARAM , StampCtx &stamp_ctx
+#  define STAMP_ARG , stamp_ctx
+#else
+#  define STAMP_DECL(base)
+#  define STAMP(i)
+#  define STAMP_WAIT_VM()
+#  define STAMP_FLUSH()
+#  define STAMP_PARAM
+#  define STAMP_ARG
+#endif
 
     struct Tiling
     {
@@ -85,6 +145,9 @@ namespace asmamd
     __device__ __forceinline__ void
     line5(double &u0, double &u1, double &u2, double &u3, double &u4, const Q &q)
     {
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 32)
+      return; // diagnostic build (results are wrong)
+#endif
       double o[N1];
 #pragma unroll
       for (int a = 0; a < N1; ++a)
@@ -231,65 +294,111 @@ namespace asmamd
       return g.store_index_near(2, K) * g.stride[2];
     }
 
-    // layout A: plane K of the lane's cell, v[j*5 + i]; MASK: constrained DoFs read as zero.
-    // Every DoF of a computable cell exists (the patch is the cell itself), so the 25
-    // loads need no predicate; lanes without a cell read offset 0.  Dirichlet masking
-    // only touches lanes whose cell lies on the boundary.
-    template <bool MASK>
-    __device__ __forceinline__ void
-    gather_plane(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int K, double (&v)[NE])
+    // ---------------------------------------------------------------------------
+    // Source staging.  A wave needs, per layer, 5 planes x 5 DoF rows of 49 consecutive DoFs.
+    // They are copied global -> LDS by 10 direct-to-LDS loads (every lane one 16-byte chunk,
+    // rows contiguous in LDS), issued one layer ahead: no vector registers are tied up while
+    // the data is in flight, every row is read from memory in full lines and exactly once
+    // per wave.  A lane then picks its 25 values from the wave-private image.
+    // ---------------------------------------------------------------------------
+    struct GatherPlan
     {
-      const double *pl = src + (c.cell_xy ? plane_offset(g, K) : 0) + c.off0;
+      int      off[GN]; // in-plane storage offset of the lane's chunk of instruction n
+      unsigned khi;     // bit n: the chunk lies in the higher of the two planes instruction n touches
+    };
+    __host__ __device__ constexpr int
+    gather_kmin(const int n)
+    {
+      return (64 * n / GCH) / N1;
+    }
+
+    __device__ __forceinline__ void
+    gather_plan_setup(const DevGrid &g, const int X0, const int Y0, GatherPlan &gp)
+    {
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      gp.khi         = 0u;
 #pragma unroll
-      for (int j = 0; j < N1; ++j)
+      for (int n = 0; n < GN; ++n)
         {
-          const double *row = pl + j * c.sy + (j == N1 - 1 ? c.yw4 : 0);
-#pragma unroll
-          for (int i = 0; i < N1 - 1; ++i)
-            v[j * 5 + i] = row[i];
-          v[j * 5 + N1 - 1] = row[N1 - 1 + c.xw4];
-        }
-      if (MASK)
-        {
-          const bool zd = g.dirichlet(2, K);
-          if (c.cell_xy && (zd || (c.xd | c.yd) != 0u))
+          const int q = 64 * n + lane;
+          int       r = q / GCH, cc = q - r * GCH;
+          if (r >= NE) // tail of the last instruction: any valid address
             {
-#pragma unroll
-              for (int j = 0; j < N1; ++j)
-#pragma unroll
-                for (int i = 0; i < N1; ++i)
-                  if (zd || (((c.xd >> i) | (c.yd >> j)) & 1u))
-                    v[j * 5 + i] = 0.;
+              r  = NE - 1;
+              cc = 0;
             }
+          const int k = r / N1, j = r - k * N1;
+          const int I = P * X0 + 2 * cc, J = P * (Y0 + w) + j;
+          // chunks outside the stored range belong to cells that are not computed: any valid address
+          const int xs = g.exists(0, I) ? g.store_index(0, I) : 0;
+          const int ys = g.exists(1, J) ? g.store_index(1, J) : 0;
+          gp.off[n]    = ys * (int)g.stride[1] + xs;
+          if (k > gather_kmin(n))
+            gp.khi |= 1u << n;
         }
     }
 
-    // layout B: row sub of the planes P cz .. P cz + 4 of the lane's cell, v[k*5 + i]
-    template <bool MASK>
+    // request the rows of cell layer cz
     __device__ __forceinline__ void
-    gather_rows(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int cz, double (&v)[NE])
+    gather_issue(const DevGrid &g, const GatherPlan &gp, const double *__restrict__ src, const int cz, double *Gw)
     {
+      long long Z[N1];
 #pragma unroll
       for (int k = 0; k < N1; ++k)
-        {
-          const double *row = src + plane_offset(g, P * cz + k) + c.rowoff;
+        Z[k] = plane_offset(g, P * cz + k);
 #pragma unroll
-          for (int i = 0; i < N1 - 1; ++i)
-            v[k * 5 + i] = row[i];
-          v[k * 5 + N1 - 1] = row[N1 - 1 + c.xw4];
+      for (int n = 0; n < GN; ++n)
+        {
+          constexpr int   last = N1 - 1;
+          const int       k0 = gather_kmin(n), k1 = k0 < last ? k0 + 1 : last;
+          const long long zo = ((gp.khi >> n) & 1u) ? Z[k1] : Z[k0];
+          const double *  q  = src + zo + gp.off[n];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)q,
+                                           (__attribute__((address_space(3))) void *)(Gw + n * 128), 16, 0, 0);
+        }
+    }
+
+    // the staged image is complete and may be read / has been read and may be overwritten
+    __device__ __forceinline__ void
+    gather_wait()
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __device__ __forceinline__ void
+    gather_release()
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // pick the lane's 25 values: LAYOUT_B ? v[k*5 + i] of row sub : v[j*5 + i] of plane sub.
+    // MASK: constrained DoFs read as zero (cz: the layer, for the z boundary planes)
+    template <bool LAYOUT_B, bool MASK>
+    __device__ __forceinline__ void
+    staged_read(const DevGrid &g, const CellLane &c, const double *Gw, const int cz, double (&v)[NE])
+    {
+      const double *base = Gw + (LAYOUT_B ? c.sub : c.sub * N1) * GROW + P * c.cl;
+#pragma unroll
+      for (int s = 0; s < N1; ++s)
+        {
+          const double *row = base + s * (LAYOUT_B ? N1 * GROW : GROW);
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            v[s * 5 + i] = row[i];
         }
       if (MASK)
         {
-          const bool     yd = (c.yd >> c.sub) & 1u;
-          const unsigned zd = (g.dirichlet(2, P * cz) ? 1u : 0u) | (g.dirichlet(2, P * cz + P) ? 16u : 0u);
-          if (c.cell_xy && (yd || zd != 0u || c.xd != 0u))
+          // Dirichlet masks of the slow register index (bits) and of the lane's own slice
+          const unsigned zd   = (g.dirichlet(2, P * cz) ? 1u : 0u) | (g.dirichlet(2, P * cz + P) ? 16u : 0u);
+          const unsigned slow = LAYOUT_B ? zd : c.yd;
+          const bool     mine = ((LAYOUT_B ? c.yd : zd) >> c.sub) & 1u;
+          if (c.cell_xy && (mine || slow != 0u || c.xd != 0u))
             {
 #pragma unroll
-              for (int k = 0; k < N1; ++k)
+              for (int s = 0; s < N1; ++s)
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
-                  if (yd || (((c.xd >> i) | (zd >> k)) & 1u))
-                    v[k * 5 + i] = 0.;
+                  if (mine || (((c.xd >> i) | (slow >> s)) & 1u))
+                    v[s * 5 + i] = 0.;
             }
         }
     }
@@ -301,6 +410,9 @@ namespace asmamd
     __device__ __forceinline__ void
     transpose5(double (&v)[NE], double *__restrict__ Tw, const CellLane &c)
     {
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 64)
+      return; // diagnostic build (results are wrong)
+#endif
       double n[NE];
       // lanes 60..63 hold no cell: they run along unpredicated (their cl = 12 slots exist)
 #pragma unroll
@@ -364,6 +476,11 @@ namespace asmamd
       if (!EpilogueOperands<MODE, NPL>::need_a)
         return;
       const double *pa = (MODE == OP_RESIDUAL) ? a.b : a.x;
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 2)
+      for (int e = 0; e < NPL * P; ++e)
+        ops.a[e] = 1.0 + e;
+      return;
+#endif
 #pragma unroll
       for (int k = 0; k < NPL; ++k)
         {
@@ -400,7 +517,11 @@ namespace asmamd
       double r[N1];
 #pragma unroll
       for (int k = 0; k < N1; ++k)
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 16)
+        r[k] = o[k * 5 + N1 - 1];
+#else
         r[k] = lane_shift5(o[k * 5 + N1 - 1], c.shl5);
+#endif
       if (c.left_ok)
         {
 #pragma unroll
@@ -418,8 +539,9 @@ namespace asmamd
     template <int MODE, int NPL>
     __device__ __forceinline__ void
     merge_y_and_store(const DevGrid &g, const CellLane &c, const TiledArgs &a, double *__restrict__ Sy, double (&o)[NE],
-                      const int K0, const EpilogueOperands<MODE, NPL> &ops)
+                      const int K0, const EpilogueOperands<MODE, NPL> &ops STAMP_PARAM)
     {
+#if !(defined(ASM_ABLATE) && (ASM_ABLATE & 8))
       // ---- y: row 4 -> row 0 of the cell above
       if (c.cell_xy && c.sub == N1 - 1)
         {
@@ -430,7 +552,9 @@ namespace asmamd
             for (int i = 0; i < N1; ++i)
               slot[k * 5 + i] = o[k * 5 + i];
         }
+      STAMP(10);
       __syncthreads();
+      STAMP(11);
       if (c.below_ok && c.sub == 0)
         {
           const double *slot = Sy + ((c.w - 1) * WX + c.cl) * YS;
@@ -440,6 +564,10 @@ namespace asmamd
             for (int i = 0; i < N1; ++i)
               o[k * 5 + i] += slot[k * 5 + i];
         }
+#endif
+      STAMP(12);
+      STAMP_WAIT_VM();
+      STAMP(13);
       // ---- fused update + store
       if (c.own_row)
         {
@@ -467,6 +595,10 @@ namespace asmamd
 #pragma unroll
               for (int i = 0; i < P; ++i)
                 rr[i] = fused_update<MODE>(a, t[i], ops.a[na ? k * P + i : 0], ops.b[nb ? k * P + i : 0]);
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 4)
+              if (rr[0] != 1.2345e300)
+                continue;
+#endif
               dbl2 lo, hi;
               lo.x = rr[0];
               lo.y = rr[1];
@@ -488,13 +620,14 @@ namespace asmamd
     // FDM sweep
     // ---------------------------------------------------------------------------
     template <int MODE, bool HAS_PRE, bool HAS_POST, bool TENSOR>
-    __global__ void __launch_bounds__(NT, 2)
+    __global__ void __launch_bounds__(NT, TY / 4)
     fdm_tiled_kernel(const DevGrid g, const DevFdm f, const TiledArgs a, const Tiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
       double *S_T   = lds;
       double *S_Y   = S_T + LDS_T;
-      double *S_tab = S_Y + LDS_Y;
+      double *S_G   = S_Y + LDS_Y;
+      double *S_tab = S_G + LDS_G;
 
       const int b  = xcd_remap(blockIdx.x, gridDim.x);
       const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
@@ -503,6 +636,9 @@ namespace asmamd
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
       double *Tw = S_T + c.w * (2 * TBUF);
+      double *Gw = S_G + c.w * GBUF;
+      GatherPlan gp;
+      gather_plan_setup(g, X0, Y0, gp);
 
       // eigen tables of tensor-product meshes live in LDS (the launcher checks n_inst <= 16)
       if (TENSOR)
@@ -515,13 +651,19 @@ namespace asmamd
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
 
-      double v[NE]; // the lane's rows (layout B); reloaded with the next layer after the store
+      double v[NE]; // the lane's rows (layout B)
       double carry[N1] = {0., 0., 0., 0., 0.};
       int    par       = 0;
-      gather_rows<false>(g, c, a.src, z_first, v);
+      gather_issue(g, gp, a.src, z_first, Gw);
+      STAMP_DECL(16)
       const int cxs = c.cell_xy ? c.cx : 0, cys = c.cell_xy ? c.cy : 0; // table rows that exist
       for (int cz = z_first; cz < Ze; ++cz)
         {
+          STAMP(0);
+          gather_wait();
+          STAMP(1);
+          staged_read<true, false>(g, c, Gw, cz, v);
+          gather_release();
           const bool active = c.cell_xy;
           int        ix = 0, iy = 0, iz = 0;
           if (active)
@@ -589,7 +731,17 @@ namespace asmamd
               sweep_slow<true>(v, q);
             }
           // ---- layout A: lane = (cell, z index c), v[b*5 + a]; y sweeps + scaling ---------
+          STAMP(2);
+          // the staged image has been consumed: request the next layer, and this layer's update operands
+#if !(defined(ASM_ABLATE) && (ASM_ABLATE & 1))
+          if (cz + 1 < Ze)
+            gather_issue(g, gp, a.src, cz + 1, Gw);
+#endif
+          EpilogueOperands<MODE, P> ops;
+          if (cz >= Zb)
+            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
           transpose5(v, Tw, c);
+          STAMP(3);
           if (TENSOR)
             sweep_slow<true>(v, Uy.fresh());
           else
@@ -597,7 +749,11 @@ namespace asmamd
               LOADQ(q, ey);
               sweep_slow<true>(v, q);
             }
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 128)
+          if (false)
+#else
           if (f.inv_table != nullptr)
+#endif
             {
               // table [iz][iy][ix][c][b][a]
               const double *inv = f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) + c.sub * NE;
@@ -605,7 +761,11 @@ namespace asmamd
               for (int e = 0; e < NE; ++e)
                 v[e] *= inv[e];
             }
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 128)
+          else if (false)
+#else
           else
+#endif
             {
               const double lzc = TENSOR ? ezl[NE + c.sub] : ezg[NE + c.sub];
 #pragma unroll
@@ -626,10 +786,9 @@ namespace asmamd
           else
             sweep_slow<false>(v, q);
           // ---- back to layout B; z and x backward sweeps, post weights --------------------
+          STAMP(4);
           transpose5(v, Tw, c);
-          EpilogueOperands<MODE, P> ops;
-          if (cz >= Zb)
-            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
+          STAMP(5);
           if (TENSOR)
             sweep_slow<false>(v, Uz.fresh());
           else
@@ -656,15 +815,17 @@ namespace asmamd
                     v[k * 5 + i] *= f.w_post[0][(cxs + 1) * N1 + i] * wyz;
                 }
             }
+          STAMP(6);
           merge_xz(c, v, carry);
+          STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops);
+              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops STAMP_ARG);
               par ^= 1;
             }
-          if (cz + 1 < Ze)
-            gather_rows<false>(g, c, a.src, cz + 1, v);
+          STAMP(8);
         }
+      STAMP_FLUSH();
 #undef LOADQ
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
         {
@@ -674,7 +835,7 @@ namespace asmamd
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             v[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops);
+          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops STAMP_ARG);
         }
     }
 
@@ -686,12 +847,13 @@ namespace asmamd
     // sweeps instead of 12 and no quadrature-point data.
     // ---------------------------------------------------------------------------
     template <int MODE>
-    __global__ void __launch_bounds__(NT, 2)
+    __global__ void __launch_bounds__(NT, TY / 4)
     laplace_cart_tiled_kernel(const DevGrid g, const DevOp op, const TiledArgs a, const Tiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
       double *S_T = lds;
       double *S_Y = S_T + LDS_T;
+      double *S_G = S_Y + LDS_Y;
 
       const int b  = xcd_remap(blockIdx.x, gridDim.x);
       const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
@@ -700,6 +862,9 @@ namespace asmamd
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
       double *Tw = S_T + c.w * (2 * TBUF);
+      double *Gw = S_G + c.w * GBUF;
+      GatherPlan gp;
+      gather_plan_setup(g, X0, Y0, gp);
 
       // reference matrices (row-major [i][j], symmetric): wave-uniform scalar operands
       const UniformSymMatrix Mm(op.M_ref), Km(op.K_ref);
@@ -716,9 +881,15 @@ namespace asmamd
       double u[NE]; // layout A on entry of a layer, layout B at its end
       double carry[N1] = {0., 0., 0., 0., 0.};
       int    par       = 0;
-      gather_plane<true>(g, c, a.src, P * z_first + c.sub, u);
+      gather_issue(g, gp, a.src, z_first, Gw);
+      STAMP_DECL(0)
       for (int cz = z_first; cz < Ze; ++cz)
         {
+          STAMP(0);
+          gather_wait();
+          STAMP(1);
+          staged_read<false, true>(g, c, Gw, cz, u);
+          gather_release();
           const double hz = op.h[2][cz + 1];
           double       t2[NE];
           // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
@@ -749,25 +920,34 @@ namespace asmamd
               u[4 * 5 + f] *= gamma;
             }
           // ---- layout B: z sweeps ------------------------------------------------------
-          transpose5(t2, Tw, c);
-          transpose5(u, Tw, c);
+          STAMP(2);
+          // the staged image has been consumed: request the next layer, and this layer's update operands
+#if !(defined(ASM_ABLATE) && (ASM_ABLATE & 1))
+          if (cz + 1 < Ze)
+            gather_issue(g, gp, a.src, cz + 1, Gw);
+#endif
           EpilogueOperands<MODE, P> ops;
           if (cz >= Zb)
             epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
+          transpose5(t2, Tw, c);
+          transpose5(u, Tw, c);
+          STAMP(3);
           sweep_slow<true>(u, Km);  // Kz (My Mx u)
           sweep_slow<true>(t2, Mm); // Mz (...)
 #pragma unroll
           for (int e = 0; e < NE; ++e)
             u[e] += t2[e];
+          STAMP(6);
           merge_xz(c, u, carry);
+          STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops);
+              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops STAMP_ARG);
               par ^= 1;
             }
-          if (cz + 1 < Ze)
-            gather_plane<true>(g, c, a.src, P * (cz + 1) + c.sub, u);
+          STAMP(8);
         }
+      STAMP_FLUSH();
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
         {
           EpilogueOperands<MODE, 1> ops;
@@ -775,7 +955,7 @@ namespace asmamd
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             u[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops);
+          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops STAMP_ARG);
         }
     }
 
@@ -886,4 +1066,16 @@ namespace asmamd
       return dispatch_fdm_mode<false, true>(g, f, a, tl, st);
     return dispatch_fdm_mode<false, false>(g, f, a, tl, st);
   }
+#ifdef ASM_STAMP
+  void
+  tiled_debug_stamps(unsigned long long out[32], bool reset)
+  {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 32 * sizeof(unsigned long long));
+    if (reset)
+      {
+        unsigned long long z[32] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+      }
+  }
+#endif
 } // namespace asmamd

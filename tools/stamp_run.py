@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycles (s_memtime) of wave 0 / workgroup 0 of the tiled FDM kernel.
+"""Diagnostic: per-phase cycles (s_memtime) of one interior wave of the tiled kernels.
 Needs a library built with -DASM_STAMP (dealii-asm_amd/abl/lib_stamp.so)."""
 import ctypes as C
 import os
@@ -18,7 +18,7 @@ b = ctx.vector(np.ones(ctx.n_owned))
 x = ctx.vector()
 lib = ctx.lib
 lib.asm_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 for _ in range(3):
     ctx.cheb_step(x, b)
 lib.asm_debug_stamps(ctx.handle, out, 1)
@@ -26,9 +26,15 @@ n = 10
 for _ in range(n):
     ctx.cheb_step(x, b)
 lib.asm_debug_stamps(ctx.handle, out, 1)
-names = ["loop top", "x,y fwd (+gather wait)", "transpose A->B", "z sweeps+scale", "transpose B->A", "y,x bwd + weights", "(unused)", "prefetch ops + carry", "acc even + gather issue", "barrier 1", "acc odd + gather issue", "barrier 2", "store epilogue", "barrier 3", "", ""]
-tot = sum(out)
+names_l = ["(loop overhead)", "wait for staged rows", "LDS read, x + y sweeps", "gather+ops issue, 2 transposes", "", "", "z sweeps", "merge x/z (lane shift)",
+           "stores issue", "", "z sweeps (LDS write wait) + y slot write", "barrier", "y slot read", "wait for update operands"]
+names_f = ["(loop overhead)", "wait for staged rows", "LDS read, tables, weights, x + z fwd", "gather+ops issue, transpose", "y fwd, scale, y bwd", "transpose",
+           "z + x bwd, weights", "merge x/z (lane shift)", "stores issue", "", "bwd sweeps + y slot write", "barrier", "y slot read", "wait for update operands"]
 layers = 17 * n
-for i in range(14):
-    print(f"{names[i]:26s} {out[i] / layers:10.0f} cycles/layer  {100.0 * out[i] / tot:5.1f}%")
-print("total per layer", tot / layers)
+for title, base, names in (("Laplace (OP_RESIDUAL)", 0, names_l), ("FDM (PC_STEP1)", 16, names_f)):
+    tot = sum(out[base + i] for i in range(16))
+    print(title)
+    for i in range(14):
+        if names[i]:
+            print(f"  {names[i]:34s} {out[base + i] / layers:10.0f} cycles/layer  {100.0 * out[base + i] / max(tot, 1):5.1f}%")
+    print(f"  total per layer {tot / layers:.0f} cycles (s_memtime ticks)")
