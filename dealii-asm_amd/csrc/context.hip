@@ -545,6 +545,8 @@ asm_create(const asm_params *p, asm_ctx **out)
   UP(ctx->basis->wq, &op.wq);
   UP(ctx->basis->M_ref, &op.M_ref);
   UP(ctx->basis->K_ref, &op.K_ref);
+  UP(ctx->basis->M_eo, &op.M_eo);
+  UP(ctx->basis->K_eo, &op.K_eo);
   // FDM data
   DevFdm &f = ctx->f;
   std::memset(&f, 0, sizeof(f));
@@ -563,6 +565,7 @@ asm_create(const asm_params *p, asm_ctx **out)
           UP(s.w_post[d], &f.w_post[d]);
         }
       UP(s.eig, &f.eig);
+      UP(s.eig_sym, &f.eig_sym);
       f.n_inst   = s.n_inst;
       f.has_pre  = s.has_pre;
       f.has_post = s.has_post;

@@ -88,6 +88,7 @@ namespace asmamd
     int tensor_inst;       // 1: instance id depends on (d, c_d) only
     const int *inst[3];    // [nc[d]] (tensor) or [ncells] (per cell): instance id of direction d
     const double *eig;     // [n_inst][m*m + m]: Q (row i, col a) then lambda
+    const int *   eig_sym; // [n_inst] 1: the first (m+1)/2 eigenvectors are even, the others odd vectors
     int           n_inst;
     int           has_pre, has_post; // weights differ from the 0/1 validity mask
     // tensor-product meshes: 1/(lx+ly+lz) for every instance triple, [iz][iy][ix][m^3], or nullptr
@@ -108,5 +109,7 @@ namespace asmamd
     const double *wq;     // [q]
     const double *M_ref;  // [i][j] reference mass matrix of FE_Q<1>(p) on [0,1]
     const double *K_ref;  // [i][j] reference stiffness matrix
+    const double *M_eo;   // degree 4: even-odd coefficients of M_ref / K_ref (numerics.h: even_odd_coefficients)
+    const double *K_eo;
   };
 } // namespace asmamd

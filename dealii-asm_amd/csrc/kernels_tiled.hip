@@ -63,7 +63,8 @@ namespace asmamd
     constexpr int GN        = (NE * GCH + 63) / 64; // wave instructions per layer (10)
     constexpr int GBUF      = GN * 128;          // doubles per wave
     constexpr int LDS_G     = TY * GBUF;
-    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_G + LDS_TAB;
+    constexpr int LDS_FLAG  = TY;                // 2 x TY ints: y-merge hand-off counters
+    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_G + LDS_TAB + LDS_FLAG;
 
 #ifdef ASM_STAMP
     // diagnostic build: cycles (s_memtime) an interior wave spends between the STAMP marks
@@ -183,6 +184,99 @@ namespace asmamd
         line5<FWD>(v[0 * 5 + f], v[1 * 5 + f], v[2 * 5 + f], v[3 * 5 + f], v[4 * 5 + f], q);
     }
 
+    // ---- even-odd forms (13 products + 8 sums per line instead of 25 products) --------------
+    // (1) matrix with columns 0..2 even and columns 3, 4 odd vectors (parity-sorted eigenvectors,
+    //     numerics.h: sort_eigenvectors_by_parity); same meaning of FWD as line5
+    template <bool FWD, typename Q>
+    __device__ __forceinline__ void
+    line5_eo(double &u0, double &u1, double &u2, double &u3, double &u4, const Q &q)
+    {
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 32)
+      return; // diagnostic build (results are wrong)
+#endif
+      if (FWD)
+        {
+          const double e0 = u0 + u4, e1 = u1 + u3, o0 = u0 - u4, o1 = u1 - u3, m = u2;
+          u0 = fma(q[2 * N1 + 0], m, fma(q[1 * N1 + 0], e1, q[0 * N1 + 0] * e0));
+          u1 = fma(q[2 * N1 + 1], m, fma(q[1 * N1 + 1], e1, q[0 * N1 + 1] * e0));
+          u2 = fma(q[2 * N1 + 2], m, fma(q[1 * N1 + 2], e1, q[0 * N1 + 2] * e0));
+          u3 = fma(q[1 * N1 + 3], o1, q[0 * N1 + 3] * o0);
+          u4 = fma(q[1 * N1 + 4], o1, q[0 * N1 + 4] * o0);
+        }
+      else
+        {
+          const double E0 = fma(q[0 * N1 + 2], u2, fma(q[0 * N1 + 1], u1, q[0 * N1 + 0] * u0));
+          const double E1 = fma(q[1 * N1 + 2], u2, fma(q[1 * N1 + 1], u1, q[1 * N1 + 0] * u0));
+          const double E2 = fma(q[2 * N1 + 2], u2, fma(q[2 * N1 + 1], u1, q[2 * N1 + 0] * u0));
+          const double O0 = fma(q[0 * N1 + 4], u4, q[0 * N1 + 3] * u3);
+          const double O1 = fma(q[1 * N1 + 4], u4, q[1 * N1 + 3] * u3);
+          u0              = E0 + O0;
+          u4              = E0 - O0;
+          u1              = E1 + O1;
+          u3              = E1 - O1;
+          u2              = E2;
+        }
+    }
+    template <bool FWD, typename Q>
+    __device__ __forceinline__ void
+    sweep_fast_eo(double (&v)[NE], const Q &q)
+    {
+#pragma unroll
+      for (int s = 0; s < N1; ++s)
+        line5_eo<FWD>(v[s * 5 + 0], v[s * 5 + 1], v[s * 5 + 2], v[s * 5 + 3], v[s * 5 + 4], q);
+    }
+    template <bool FWD, typename Q>
+    __device__ __forceinline__ void
+    sweep_slow_eo(double (&v)[NE], const Q &q)
+    {
+#pragma unroll
+      for (int f = 0; f < N1; ++f)
+        line5_eo<FWD>(v[0 * 5 + f], v[1 * 5 + f], v[2 * 5 + f], v[3 * 5 + f], v[4 * 5 + f], q);
+    }
+
+    // (2) symmetric matrix invariant under (i, j) -> (4-i, 4-j), given by its 9 even-odd
+    //     coefficients c (numerics.h: even_odd_coefficients).  A line is split into its even part
+    //     (e0, e1, m) and odd part (o0, o1); the parts of several products can be accumulated
+    //     before the outputs are recombined.
+    struct EvenOdd
+    {
+      double e0, e1, m, o0, o1;
+    };
+    __device__ __forceinline__ EvenOdd
+    eo_split(const double u0, const double u1, const double u2, const double u3, const double u4)
+    {
+      return {u0 + u4, u1 + u3, u2, u0 - u4, u1 - u3};
+    }
+    // r = A x (ACC = false) or r += A x, both in split form (S0, S1, y2, D0, D1 stored as e0, e1, m, o0, o1)
+    template <bool ACC, typename C>
+    __device__ __forceinline__ void
+    eo_apply(EvenOdd &r, const EvenOdd &x, const C &c)
+    {
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 32)
+      r = x;
+      return; // diagnostic build (results are wrong)
+#endif
+      r.e0 = fma(c[2], x.m, fma(c[1], x.e1, ACC ? fma(c[0], x.e0, r.e0) : c[0] * x.e0));
+      r.e1 = fma(c[4], x.m, fma(c[3], x.e1, ACC ? fma(c[1], x.e0, r.e1) : c[1] * x.e0));
+      r.m  = fma(c[5], x.m, fma(c[4], x.e1, ACC ? fma(c[2], x.e0, r.m) : c[2] * x.e0));
+      r.o0 = fma(c[7], x.o1, ACC ? fma(c[6], x.o0, r.o0) : c[6] * x.o0);
+      r.o1 = fma(c[8], x.o1, ACC ? fma(c[7], x.o0, r.o1) : c[7] * x.o0);
+    }
+    __device__ __forceinline__ void
+    eo_join(const EvenOdd &r, double &u0, double &u1, double &u2, double &u3, double &u4)
+    {
+      u0 = r.e0 + r.o0;
+      u4 = r.e0 - r.o0;
+      u1 = r.e1 + r.o1;
+      u3 = r.e1 - r.o1;
+      u2 = r.m;
+    }
+    __device__ __forceinline__ EvenOdd
+    eo_scale(const EvenOdd &x, const double f)
+    {
+      return {x.e0 * f, x.e1 * f, x.m * f, x.o0 * f, x.o1 * f};
+    }
+
     // a wave-uniform 5x5 matrix in global memory: the loads become scalar loads and the
     // entries scalar operands of the FMAs, so they cost no vector registers
     struct UniformMatrix
@@ -204,16 +298,14 @@ namespace asmamd
       }
     };
 
-    // the same for a matrix that is symmetric and invariant under (i, j) -> (4-i, 4-j), like the
-    // reference mass and stiffness matrices (numerics.h makes that hold bitwise): 9 distinct
-    // entries, so two such matrices stay resident in scalar registers
-    struct UniformSymMatrix
+    // the 9 even-odd coefficients of a reference matrix: two such tables stay resident in scalar registers
+    struct UniformCoefficients
     {
       const __attribute__((address_space(4))) double *p;
-      __device__ __forceinline__ explicit UniformSymMatrix(const double *q)
+      __device__ __forceinline__ explicit UniformCoefficients(const double *q)
         : p((const __attribute__((address_space(4))) double *)q)
       {}
-      __device__ __forceinline__ double operator[](const int e) const { return p[symmetric_entry(e / N1, e % N1, N1)]; }
+      __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
     };
 
     __device__ __forceinline__ void
@@ -346,8 +438,13 @@ namespace asmamd
 #pragma unroll
       for (int k = 0; k < N1; ++k)
         Z[k] = plane_offset(g, P * cz + k);
+#if defined(ASM_DMA_N)
+      constexpr int gn = ASM_DMA_N; // diagnostic build: fewer rows (results are wrong)
+#else
+      constexpr int gn = GN;
+#endif
 #pragma unroll
-      for (int n = 0; n < GN; ++n)
+      for (int n = 0; n < gn; ++n)
         {
           constexpr int   last = N1 - 1;
           const int       k0 = gather_kmin(n), k1 = k0 < last ? k0 + 1 : last;
@@ -485,6 +582,9 @@ namespace asmamd
       for (int k = 0; k < NPL; ++k)
         {
           const long long off = plane_offset(g, K0 + k) + c.rowoff;
+#if defined(ASM_OPS_PRED)
+          if (c.own_row)
+#endif
 #pragma unroll
           for (int i = 0; i < P; ++i)
             {
@@ -536,13 +636,35 @@ namespace asmamd
         }
     }
 
+    // Hand-off of the y-merge slots between neighbouring waves.  A wave only depends on the wave
+    // below it (which produces its row 0 share) and, for slot reuse, on the wave above it, so the
+    // waves of a workgroup are not forced through a common barrier every layer and may drift apart
+    // by up to two layers: their memory phases and compute phases then overlap.
+    // prod[w] = last layer whose slot wave w has written, cons[w] = last layer wave w has read.
+    struct YSync
+    {
+      volatile int *prod, *cons;
+      int           seq; // running number of the merge (same in every wave)
+    };
+    __device__ __forceinline__ void
+    spin_until(volatile int *flag, const int n)
+    {
+      while (__builtin_amdgcn_readfirstlane(*flag) < n)
+        __builtin_amdgcn_s_sleep(1);
+    }
+
     template <int MODE, int NPL>
     __device__ __forceinline__ void
     merge_y_and_store(const DevGrid &g, const CellLane &c, const TiledArgs &a, double *__restrict__ Sy, double (&o)[NE],
-                      const int K0, const EpilogueOperands<MODE, NPL> &ops STAMP_PARAM)
+                      const int K0, const EpilogueOperands<MODE, NPL> &ops, YSync &ys STAMP_PARAM)
     {
 #if !(defined(ASM_ABLATE) && (ASM_ABLATE & 8))
       // ---- y: row 4 -> row 0 of the cell above
+#if defined(ASM_FLAGS)
+      const int n = ys.seq++;
+      if (c.w + 1 < TY)
+        spin_until(ys.cons + c.w + 1, n - 2); // the slot's previous content (two layers ago) has been read
+#endif
       if (c.cell_xy && c.sub == N1 - 1)
         {
           double *slot = Sy + (c.w * WX + c.cl) * YS;
@@ -553,7 +675,16 @@ namespace asmamd
               slot[k * 5 + i] = o[k * 5 + i];
         }
       STAMP(10);
+#if defined(ASM_FLAGS)
+      // LDS executes a wave's instructions in order: whoever sees the counter sees the slot
+      asm volatile("" ::: "memory");
+      ys.prod[c.w] = n;
+      if (c.w >= 1)
+        spin_until(ys.prod + c.w - 1, n);
+      asm volatile("" ::: "memory");
+#else
       __syncthreads();
+#endif
       STAMP(11);
       if (c.below_ok && c.sub == 0)
         {
@@ -564,6 +695,10 @@ namespace asmamd
             for (int i = 0; i < N1; ++i)
               o[k * 5 + i] += slot[k * 5 + i];
         }
+#endif
+#if defined(ASM_FLAGS)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ys.cons[c.w] = n;
 #endif
       STAMP(12);
       STAMP_WAIT_VM();
@@ -640,13 +775,21 @@ namespace asmamd
       GatherPlan gp;
       gather_plan_setup(g, X0, Y0, gp);
 
+      YSync ys;
+      ys.prod = (volatile int *)(S_tab + LDS_TAB);
+      ys.cons = ys.prod + TY;
+      ys.seq  = 0;
+      if (threadIdx.x < 2 * TY)
+        ys.prod[threadIdx.x] = -1;
       // eigen tables of tensor-product meshes live in LDS (the launcher checks n_inst <= 16)
       if (TENSOR)
-        {
-          for (int e = threadIdx.x; e < f.n_inst * EIG; e += NT)
-            S_tab[e] = f.eig[e];
-          __syncthreads();
-        }
+        for (int e = threadIdx.x; e < f.n_inst * EIG; e += NT)
+          S_tab[e] = f.eig[e];
+      __syncthreads();
+#if defined(ASM_SKEW)
+      for (int i = 0; i < (int)(threadIdx.x >> 6) * ASM_SKEW; ++i)
+        __builtin_amdgcn_s_sleep(16);
+#endif
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
@@ -690,6 +833,10 @@ namespace asmamd
           const int          ix_u  = __builtin_amdgcn_readlane(ix, lane0);
           const bool         x_uniform = TENSOR && __all(!active || ix == ix_u);
           const UniformMatrix Ux(f.eig + (long long)ix_u * EIG);
+          // parity-sorted eigenvectors (cells without a Dirichlet face): even-odd sweeps
+          const bool sym_x = x_uniform && f.eig_sym[ix_u] != 0;
+          const bool sym_y = TENSOR && f.eig_sym[__builtin_amdgcn_readfirstlane(iy_u)] != 0;
+          const bool sym_z = TENSOR && f.eig_sym[__builtin_amdgcn_readfirstlane(iz_u)] != 0;
 #define LOADQ(q, d) \
   do                \
     {               \
@@ -716,14 +863,16 @@ namespace asmamd
                     v[k * 5 + i] *= f.w_pre[0][(cxs + 1) * N1 + i] * wyz;
                 }
             }
-          if (x_uniform)
-            sweep_fast<true>(v, Ux.fresh());
+          if (sym_x)
+            sweep_fast_eo<true>(v, Ux.fresh());
           else
             {
               LOADQ(q, ex);
               sweep_fast<true>(v, q);
             }
-          if (TENSOR)
+          if (sym_z)
+            sweep_slow_eo<true>(v, Uz.fresh());
+          else if (TENSOR)
             sweep_slow<true>(v, Uz.fresh());
           else
             {
@@ -742,7 +891,9 @@ namespace asmamd
             epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
           transpose5(v, Tw, c);
           STAMP(3);
-          if (TENSOR)
+          if (sym_y)
+            sweep_slow_eo<true>(v, Uy.fresh());
+          else if (TENSOR)
             sweep_slow<true>(v, Uy.fresh());
           else
             {
@@ -781,7 +932,9 @@ namespace asmamd
                     v[bb * 5 + aa] *= r;
                   }
             }
-          if (TENSOR)
+          if (sym_y)
+            sweep_slow_eo<false>(v, Uy.fresh());
+          else if (TENSOR)
             sweep_slow<false>(v, Uy.fresh());
           else
             sweep_slow<false>(v, q);
@@ -789,15 +942,17 @@ namespace asmamd
           STAMP(4);
           transpose5(v, Tw, c);
           STAMP(5);
-          if (TENSOR)
+          if (sym_z)
+            sweep_slow_eo<false>(v, Uz.fresh());
+          else if (TENSOR)
             sweep_slow<false>(v, Uz.fresh());
           else
             {
               LOADQ(q, ez);
               sweep_slow<false>(v, q);
             }
-          if (x_uniform)
-            sweep_fast<false>(v, Ux.fresh());
+          if (sym_x)
+            sweep_fast_eo<false>(v, Ux.fresh());
           else
             {
               LOADQ(q, ex);
@@ -820,7 +975,7 @@ namespace asmamd
           STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops STAMP_ARG);
+              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops, ys STAMP_ARG);
               par ^= 1;
             }
           STAMP(8);
@@ -835,7 +990,7 @@ namespace asmamd
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             v[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops STAMP_ARG);
+          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops, ys STAMP_ARG);
         }
     }
 
@@ -866,8 +1021,20 @@ namespace asmamd
       GatherPlan gp;
       gather_plan_setup(g, X0, Y0, gp);
 
-      // reference matrices (row-major [i][j], symmetric): wave-uniform scalar operands
-      const UniformSymMatrix Mm(op.M_ref), Km(op.K_ref);
+      YSync ys;
+      ys.prod = (volatile int *)(S_G + LDS_G + LDS_TAB);
+      ys.cons = ys.prod + TY;
+      ys.seq  = 0;
+      if (threadIdx.x < 2 * TY)
+        ys.prod[threadIdx.x] = -1;
+      __syncthreads();
+#if defined(ASM_SKEW)
+      for (int i = 0; i < (int)(threadIdx.x >> 6) * ASM_SKEW; ++i)
+        __builtin_amdgcn_s_sleep(16);
+#endif
+
+      // even-odd coefficients of the reference matrices: wave-uniform scalar operands
+      const UniformCoefficients Mm(op.M_eo), Km(op.K_eo);
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
@@ -893,31 +1060,31 @@ namespace asmamd
           const double hz = op.h[2][cz + 1];
           double       t2[NE];
           // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
-          // ---- layout A: x and y sweeps ------------------------------------------------
+          // ---- layout A: x and y sweeps (even-odd form) ----------------------------------
+          // rows: t2 = Kx u, u = Mx u
 #pragma unroll
-          for (int e = 0; e < NE; ++e)
-            t2[e] = u[e];
-          sweep_fast<true>(t2, Km); // t2 = Kx u
-          sweep_fast<true>(u, Mm);  // u  = Mx u
+          for (int j = 0; j < N1; ++j)
+            {
+              const EvenOdd x = eo_split(u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);
+              EvenOdd       r;
+              eo_apply<false>(r, x, Km);
+              eo_join(r, t2[j * 5 + 0], t2[j * 5 + 1], t2[j * 5 + 2], t2[j * 5 + 3], t2[j * 5 + 4]);
+              eo_apply<false>(r, x, Mm);
+              eo_join(r, u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);
+            }
           const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
-          // column by column: t2 <- alpha My t2 + beta Ky u  (needs Mz),  u <- gamma My u  (needs Kz)
+          // columns: t2 <- My (alpha t2) + Ky (beta u)  (needs Mz),  u <- My (gamma u)  (needs Kz)
 #pragma unroll
           for (int f = 0; f < N1; ++f)
             {
-              double k0 = u[0 * 5 + f], k1 = u[1 * 5 + f], k2 = u[2 * 5 + f], k3 = u[3 * 5 + f], k4 = u[4 * 5 + f];
-              line5<true>(k0, k1, k2, k3, k4, Km); // Ky (Mx u)
-              line5<true>(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f], Mm);
-              line5<true>(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f], Mm);
-              t2[0 * 5 + f] = fma(beta, k0, alpha * t2[0 * 5 + f]);
-              t2[1 * 5 + f] = fma(beta, k1, alpha * t2[1 * 5 + f]);
-              t2[2 * 5 + f] = fma(beta, k2, alpha * t2[2 * 5 + f]);
-              t2[3 * 5 + f] = fma(beta, k3, alpha * t2[3 * 5 + f]);
-              t2[4 * 5 + f] = fma(beta, k4, alpha * t2[4 * 5 + f]);
-              u[0 * 5 + f] *= gamma;
-              u[1 * 5 + f] *= gamma;
-              u[2 * 5 + f] *= gamma;
-              u[3 * 5 + f] *= gamma;
-              u[4 * 5 + f] *= gamma;
+              const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);
+              const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
+              EvenOdd       r;
+              eo_apply<false>(r, eo_scale(xa, alpha), Mm);
+              eo_apply<true>(r, eo_scale(xb, beta), Km);
+              eo_join(r, t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);
+              eo_apply<false>(r, eo_scale(xb, gamma), Mm);
+              eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
             }
           // ---- layout B: z sweeps ------------------------------------------------------
           STAMP(2);
@@ -932,17 +1099,23 @@ namespace asmamd
           transpose5(t2, Tw, c);
           transpose5(u, Tw, c);
           STAMP(3);
-          sweep_slow<true>(u, Km);  // Kz (My Mx u)
-          sweep_slow<true>(t2, Mm); // Mz (...)
+          // columns: u <- Kz u + Mz t2
 #pragma unroll
-          for (int e = 0; e < NE; ++e)
-            u[e] += t2[e];
+          for (int f = 0; f < N1; ++f)
+            {
+              const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);
+              const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
+              EvenOdd       r;
+              eo_apply<false>(r, xa, Mm);
+              eo_apply<true>(r, xb, Km);
+              eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
+            }
           STAMP(6);
           merge_xz(c, u, carry);
           STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops STAMP_ARG);
+              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops, ys STAMP_ARG);
               par ^= 1;
             }
           STAMP(8);
@@ -955,7 +1128,7 @@ namespace asmamd
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             u[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops STAMP_ARG);
+          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops, ys STAMP_ARG);
         }
     }
 

@@ -120,6 +120,7 @@ namespace asmamd
     bool                tensor_inst;
     std::vector<int>    inst[3]; // [nc+2] or [ext cells]
     std::vector<double> eig;     // [n_inst][m*m+m]
+    std::vector<int>    eig_sym; // [n_inst] 1: eigenvectors sorted by parity (numerics.h: sort_eigenvectors_by_parity)
     int                 n_inst;
     std::vector<double> w_pre[3], w_post[3]; // [nc+2][m]
     bool                has_pre, has_post;
@@ -643,6 +644,7 @@ namespace asmamd
     // ---- FDM instances ---------------------------------------------------
     std::map<std::vector<double>, int> cache;
     s.eig.clear();
+    s.eig_sym.clear();
     const auto get_instance = [&](const double h3[3], const int bc_lo, const int bc_hi) -> int {
       std::vector<double> key = {h3[0], h3[1], h3[2], (double)bc_lo, (double)bc_hi};
       if (vertex)
@@ -656,6 +658,7 @@ namespace asmamd
       else
         fdm_matrices_element(b, h3, bc_lo, bc_hi, n, M, K);
       generalized_eigen(m, M, K, lam, Q);
+      s.eig_sym.push_back(sort_eigenvectors_by_parity(m, Q, lam) ? 1 : 0);
       const int id = cache.size();
       cache[key]   = id;
       s.eig.insert(s.eig.end(), Q.begin(), Q.end());
