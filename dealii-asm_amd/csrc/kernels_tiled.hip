@@ -308,6 +308,15 @@ namespace asmamd
       __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
     };
 
+    // read-only table entry at a wave-uniform index: a scalar load (s_load), so that it does not
+    // enter the vector memory counter the staged rows and update operands are tracked with
+    template <typename T>
+    __device__ __forceinline__ T
+    uniform_load(const T *table, const int idx)
+    {
+      return ((const __attribute__((address_space(4))) T *)table)[__builtin_amdgcn_readfirstlane(idx)];
+    }
+
     __device__ __forceinline__ void
     load25(double (&q)[NE], const double *__restrict__ src)
     {
@@ -434,6 +443,9 @@ namespace asmamd
     __device__ __forceinline__ void
     gather_issue(const DevGrid &g, const GatherPlan &gp, const double *__restrict__ src, const int cz, double *Gw)
     {
+      // LDS byte address of the wave's image (wave-uniform)
+      const unsigned lds_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)Gw);
       long long Z[N1];
 #pragma unroll
       for (int k = 0; k < N1; ++k)
@@ -450,8 +462,16 @@ namespace asmamd
           const int       k0 = gather_kmin(n), k1 = k0 < last ? k0 + 1 : last;
           const long long zo = ((gp.khi >> n) & 1u) ? Z[k1] : Z[k0];
           const double *  q  = src + zo + gp.off[n];
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)q,
-                                           (__attribute__((address_space(3))) void *)(Gw + n * 128), 16, 0, 0);
+          // Issued as an asm statement: hipcc would otherwise drain every pending vector memory
+          // operation (vmcnt(0)) at the next LDS access that might alias the destination, i.e. at
+          // the transposes right behind this request.  The asm form is invisible to the compiler's
+          // wait-count bookkeeping; gather_wait() is the explicit wait that covers it.
+          // M0 holds the wave-uniform LDS destination and is restored afterwards.
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(q), "s"(lds_base + n * 1024u)
+                       : "memory");
         }
     }
 
@@ -504,13 +524,20 @@ namespace asmamd
     // v'[s*5 + f] = (value v[sub*5 + f] of the cell's lane s), i.e. the lane index and the
     // slow register index change places (layout A <-> B).  One fast index f per round
     // through the wave-private buffer (2 x 320 doubles).
+    // The LDS executes the instructions of one wave in order, so a read sees the partner lanes'
+    // earlier writes and a later write cannot overtake an earlier read of the same words: no
+    // s_waitcnt is needed between the rounds, only the compiler must not reorder the accesses.
     __device__ __forceinline__ void
     transpose5(double (&v)[NE], double *__restrict__ Tw, const CellLane &c)
     {
 #if defined(ASM_ABLATE) && (ASM_ABLATE & 64)
       return; // diagnostic build (results are wrong)
 #endif
-      double n[NE];
+#if defined(ASM_TRANSPOSE_WAIT)
+#  define TRANSPOSE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#  define TRANSPOSE_FENCE() asm volatile("" ::: "memory")
+#endif
       // lanes 60..63 hold no cell: they run along unpredicated (their cl = 12 slots exist)
 #pragma unroll
       for (int f = 0; f < N1; ++f)
@@ -519,17 +546,13 @@ namespace asmamd
 #pragma unroll
           for (int s = 0; s < N1; ++s)
             buf[c.lane * N1 + s] = v[s * 5 + f];
-          // the partner lanes' stores must be visible: LDS executes a wave's
-          // instructions in order; keep the compiler from moving the loads up
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          TRANSPOSE_FENCE();
 #pragma unroll
           for (int s = 0; s < N1; ++s)
-            n[s * 5 + f] = buf[(c.cl * N1 + s) * N1 + c.sub];
+            v[s * 5 + f] = buf[(c.cl * N1 + s) * N1 + c.sub];
+          TRANSPOSE_FENCE();
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int e = 0; e < NE; ++e)
-        v[e] = n[e];
+#undef TRANSPOSE_FENCE
     }
 
     // value of lane - 5 (the same row / plane of the x-neighbour cell)
@@ -701,35 +724,26 @@ namespace asmamd
       ys.cons[c.w] = n;
 #endif
       STAMP(12);
-      STAMP_WAIT_VM();
+      // the next layer's staged rows (requested long ago) and the update operands have arrived;
+      // waiting here, before this layer's stores are issued, keeps the stores out of the wait
+      gather_wait();
       STAMP(13);
       // ---- fused update + store
       if (c.own_row)
         {
-          const bool yd = (c.yd >> c.sub) & 1u;
+          constexpr bool na = EpilogueOperands<MODE, NPL>::need_a, nb = EpilogueOperands<MODE, NPL>::need_b;
+          const bool     yd = (c.yd >> c.sub) & 1u;
+          // all stores are issued back to back; constrained DoFs (boundary cells only) are put
+          // right afterwards: their source values would otherwise make every plane's stores wait
+          // for the plane before
 #pragma unroll
           for (int k = 0; k < NPL; ++k)
             {
               const long long off = plane_offset(g, K0 + k) + c.rowoff;
-              const unsigned  cm  = (yd || g.dirichlet(2, K0 + k)) ? 0x1fu : c.xd;
-              double          t[N1];
-#pragma unroll
-              for (int i = 0; i < N1; ++i)
-                t[i] = o[k * 5 + i];
-              if (cm != 0u)
-                {
-                  // constrained DoFs: zero (plain product) or the identity row (fused modes:
-                  // (A x)_c = x_c, matrix_free_internal.h:247-255; unit rows of P^-1)
-#pragma unroll
-                  for (int i = 0; i < N1; ++i)
-                    if ((cm >> i) & 1u)
-                      t[i] = (MODE == OP_PLAIN || MODE == PC_PLAIN) ? 0. : a.src[off + i];
-                }
-              constexpr bool na = EpilogueOperands<MODE, NPL>::need_a, nb = EpilogueOperands<MODE, NPL>::need_b;
-              double         rr[P];
+              double          rr[P];
 #pragma unroll
               for (int i = 0; i < P; ++i)
-                rr[i] = fused_update<MODE>(a, t[i], ops.a[na ? k * P + i : 0], ops.b[nb ? k * P + i : 0]);
+                rr[i] = fused_update<MODE>(a, o[k * 5 + i], ops.a[na ? k * P + i : 0], ops.b[nb ? k * P + i : 0]);
 #if defined(ASM_ABLATE) && (ASM_ABLATE & 4)
               if (rr[0] != 1.2345e300)
                 continue;
@@ -741,11 +755,43 @@ namespace asmamd
               hi.y = rr[3];
               *(dbl2_u *)(a.dst + off)     = lo;
               *(dbl2_u *)(a.dst + off + 2) = hi;
-              if (c.own_c4)
+            }
+          // constrained DoFs: zero (plain product) or the identity row (fused modes:
+          // (A x)_c = x_c, matrix_free_internal.h:247-255; unit rows of P^-1)
+          const unsigned zdm = (g.dirichlet(2, K0) ? 1u : 0u) | ((NPL == P && g.dirichlet(2, K0 + P)) ? 16u : 0u);
+          if (c.own_c4)
+            {
+              // the block's last column (dst may alias x_old: every operand is read before the store)
+#pragma unroll
+              for (int k = 0; k < NPL; ++k)
                 {
-                  const double oa   = na ? ((MODE == OP_RESIDUAL) ? a.b : a.x)[off + P] : 0.;
-                  const double ob   = nb ? a.x_old[off + P] : 0.;
-                  a.dst[off + P]    = fused_update<MODE>(a, t[P], oa, ob);
+                  const long long off = plane_offset(g, K0 + k) + c.rowoff + P;
+                  const bool      con = yd || ((zdm >> k) & 1u) || ((c.xd >> P) & 1u);
+                  double          t   = o[k * 5 + P];
+                  if (con)
+                    t = (MODE == OP_PLAIN || MODE == PC_PLAIN) ? 0. : a.src[off];
+                  const double oa = na ? ((MODE == OP_RESIDUAL) ? a.b : a.x)[off] : 0.;
+                  const double ob = nb ? a.x_old[off] : 0.;
+                  a.dst[off]      = fused_update<MODE>(a, t, oa, ob);
+                }
+            }
+          if (yd || (c.xd & 0xfu) != 0u || (zdm & ((1u << NPL) - 1u)) != 0u)
+            {
+#pragma unroll
+              for (int k = 0; k < NPL; ++k)
+                {
+                  const unsigned cm = (yd || ((zdm >> k) & 1u)) ? 0xfu : (c.xd & 0xfu);
+                  if (cm != 0u)
+                    {
+                      const long long off = plane_offset(g, K0 + k) + c.rowoff;
+#pragma unroll
+                      for (int i = 0; i < P; ++i)
+                        if ((cm >> i) & 1u)
+                          {
+                            const double t = (MODE == OP_PLAIN || MODE == PC_PLAIN) ? 0. : a.src[off + i];
+                            a.dst[off + i] = fused_update<MODE>(a, t, ops.a[na ? k * P + i : 0], ops.b[nb ? k * P + i : 0]);
+                          }
+                    }
                 }
             }
         }
@@ -798,24 +844,50 @@ namespace asmamd
       double carry[N1] = {0., 0., 0., 0., 0.};
       int    par       = 0;
       gather_issue(g, gp, a.src, z_first, Gw);
+      gather_wait();
       STAMP_DECL(16)
       const int cxs = c.cell_xy ? c.cx : 0, cys = c.cell_xy ? c.cy : 0; // table rows that exist
+      // tensor-product meshes: the x and y instances of a lane do not change along z
+      const bool active = c.cell_xy;
+      int        ix_t = 0, iy_t = 0;
+      if (TENSOR && active)
+        {
+          ix_t = f.inst[0][c.cx + 1];
+          iy_t = f.inst[1][c.cy + 1];
+        }
+      const int iy_u = TENSOR ? uniform_load(f.inst[1], min(max(Y0 + (int)(threadIdx.x >> 6), -1), g.nc[1]) + 1) : 0;
+      // the x and y factors of the weights are kept in registers: loading them layer by layer
+      // would put vector loads (and waits for everything issued before them) into the layer
+      double wpre_x[N1], wpre_y = 1., wpost_x[N1], wpost_y = 1.;
+      if (HAS_PRE)
+        {
+          wpre_y = f.w_pre[1][(cys + 1) * N1 + c.sub];
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            wpre_x[i] = f.w_pre[0][(cxs + 1) * N1 + i];
+        }
+      if (HAS_POST)
+        {
+          wpost_y = f.w_post[1][(cys + 1) * N1 + c.sub];
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            wpost_x[i] = f.w_post[0][(cxs + 1) * N1 + i];
+        }
       for (int cz = z_first; cz < Ze; ++cz)
         {
           STAMP(0);
-          gather_wait();
-          STAMP(1);
           staged_read<true, false>(g, c, Gw, cz, v);
           gather_release();
-          const bool active = c.cell_xy;
-          int        ix = 0, iy = 0, iz = 0;
-          if (active)
+          int ix = ix_t, iy = iy_t, iz = 0;
+          if (TENSOR)
+            iz = active ? uniform_load(f.inst[2], cz + 1) : 0;
+          else if (active)
             {
               const long long ce =
                 (c.cx + 1) + (long long)(g.nc[0] + 2) * ((c.cy + 1) + (long long)(g.nc[1] + 2) * (cz + 1));
-              ix = TENSOR ? f.inst[0][c.cx + 1] : f.inst[0][ce];
-              iy = TENSOR ? f.inst[1][c.cy + 1] : f.inst[1][ce];
-              iz = TENSOR ? f.inst[2][cz + 1] : f.inst[2][ce];
+              ix = f.inst[0][ce];
+              iy = f.inst[1][ce];
+              iz = f.inst[2][ce];
             }
           // two address spaces, two pointer sets: a merged pointer would compile to flat loads
           const double *exl = S_tab + ix * EIG, *eyl = S_tab + iy * EIG, *ezl = S_tab + iz * EIG;
@@ -823,8 +895,7 @@ namespace asmamd
                        *ezg = f.eig + (long long)iz * EIG;
           // tensor-product meshes: the y and z matrices depend on the cell row / layer only
           // (taken from the row / layer index, not from a lane: lane 0 may hold a cell that does not exist)
-          const int iy_u = TENSOR ? f.inst[1][min(max(Y0 + (int)(threadIdx.x >> 6), -1), g.nc[1]) + 1] : 0;
-          const int iz_u = TENSOR ? f.inst[2][cz + 1] : 0;
+          const int iz_u = TENSOR ? uniform_load(f.inst[2], cz + 1) : 0;
           const UniformMatrix Uy(f.eig + (long long)__builtin_amdgcn_readfirstlane(iy_u) * EIG),
             Uz(f.eig + (long long)__builtin_amdgcn_readfirstlane(iz_u) * EIG);
           // the x matrix is wave-uniform too unless the cell row touches a boundary column
@@ -834,9 +905,9 @@ namespace asmamd
           const bool         x_uniform = TENSOR && __all(!active || ix == ix_u);
           const UniformMatrix Ux(f.eig + (long long)ix_u * EIG);
           // parity-sorted eigenvectors (cells without a Dirichlet face): even-odd sweeps
-          const bool sym_x = x_uniform && f.eig_sym[ix_u] != 0;
-          const bool sym_y = TENSOR && f.eig_sym[__builtin_amdgcn_readfirstlane(iy_u)] != 0;
-          const bool sym_z = TENSOR && f.eig_sym[__builtin_amdgcn_readfirstlane(iz_u)] != 0;
+          const bool sym_x = x_uniform && uniform_load(f.eig_sym, ix_u) != 0;
+          const bool sym_y = TENSOR && uniform_load(f.eig_sym, iy_u) != 0;
+          const bool sym_z = TENSOR && uniform_load(f.eig_sym, iz_u) != 0;
 #define LOADQ(q, d) \
   do                \
     {               \
@@ -853,14 +924,13 @@ namespace asmamd
           // ---- layout B: lane = (cell, y row j), v[k*5 + i]; x and z forward sweeps -------
           if (HAS_PRE)
             {
-              const double wy = f.w_pre[1][(cys + 1) * N1 + c.sub];
 #pragma unroll
               for (int k = 0; k < N1; ++k)
                 {
-                  const double wyz = f.w_pre[2][(cz + 1) * N1 + k] * wy;
+                  const double wyz = uniform_load(f.w_pre[2], (cz + 1) * N1 + k) * wpre_y;
 #pragma unroll
                   for (int i = 0; i < N1; ++i)
-                    v[k * 5 + i] *= f.w_pre[0][(cxs + 1) * N1 + i] * wyz;
+                    v[k * 5 + i] *= wpre_x[i] * wyz;
                 }
             }
           if (sym_x)
@@ -881,14 +951,6 @@ namespace asmamd
             }
           // ---- layout A: lane = (cell, z index c), v[b*5 + a]; y sweeps + scaling ---------
           STAMP(2);
-          // the staged image has been consumed: request the next layer, and this layer's update operands
-#if !(defined(ASM_ABLATE) && (ASM_ABLATE & 1))
-          if (cz + 1 < Ze)
-            gather_issue(g, gp, a.src, cz + 1, Gw);
-#endif
-          EpilogueOperands<MODE, P> ops;
-          if (cz >= Zb)
-            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
           transpose5(v, Tw, c);
           STAMP(3);
           if (sym_y)
@@ -932,6 +994,16 @@ namespace asmamd
                     v[bb * 5 + aa] *= r;
                   }
             }
+          // request the next layer's rows and this layer's update operands: behind the last vector
+          // loads of the layer (eigenvalue table), so that nothing has to wait for them before the
+          // merge; they have until the store phase / the next layer to arrive
+#if !(defined(ASM_ABLATE) && (ASM_ABLATE & 1))
+          if (cz + 1 < Ze)
+            gather_issue(g, gp, a.src, cz + 1, Gw);
+#endif
+          EpilogueOperands<MODE, P> ops;
+          if (cz >= Zb)
+            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
           if (sym_y)
             sweep_slow_eo<false>(v, Uy.fresh());
           else if (TENSOR)
@@ -960,14 +1032,13 @@ namespace asmamd
             }
           if (HAS_POST)
             {
-              const double wy = f.w_post[1][(cys + 1) * N1 + c.sub];
 #pragma unroll
               for (int k = 0; k < N1; ++k)
                 {
-                  const double wyz = f.w_post[2][(cz + 1) * N1 + k] * wy;
+                  const double wyz = uniform_load(f.w_post[2], (cz + 1) * N1 + k) * wpost_y;
 #pragma unroll
                   for (int i = 0; i < N1; ++i)
-                    v[k * 5 + i] *= f.w_post[0][(cxs + 1) * N1 + i] * wyz;
+                    v[k * 5 + i] *= wpost_x[i] * wyz;
                 }
             }
           STAMP(6);
@@ -978,6 +1049,8 @@ namespace asmamd
               merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops, ys STAMP_ARG);
               par ^= 1;
             }
+          else
+            gather_wait(); // halo layer: nothing stored, only the carry leaves it
           STAMP(8);
         }
       STAMP_FLUSH();
@@ -1049,15 +1122,14 @@ namespace asmamd
       double carry[N1] = {0., 0., 0., 0., 0.};
       int    par       = 0;
       gather_issue(g, gp, a.src, z_first, Gw);
+      gather_wait();
       STAMP_DECL(0)
       for (int cz = z_first; cz < Ze; ++cz)
         {
           STAMP(0);
-          gather_wait();
-          STAMP(1);
           staged_read<false, true>(g, c, Gw, cz, u);
           gather_release();
-          const double hz = op.h[2][cz + 1];
+          const double hz = uniform_load(op.h[2], cz + 1);
           double       t2[NE];
           // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
           // ---- layout A: x and y sweeps (even-odd form) ----------------------------------
@@ -1118,6 +1190,8 @@ namespace asmamd
               merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops, ys STAMP_ARG);
               par ^= 1;
             }
+          else
+            gather_wait(); // halo layer: nothing stored, only the carry leaves it
           STAMP(8);
         }
       STAMP_FLUSH();
