@@ -118,6 +118,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ASM_BENCH_SHARE_DEVICE"):  # rehearsal of the N>1 path on a one-GPU box: every rank on device 0
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world

@@ -111,6 +111,8 @@ EXPORTED_SYMBOLS = [
     "asm_kernel_variant_in_use",
     "asm_synchronize",
     "asm_time_calls",
+    "asm_debug_external_exchange",
+    "asm_debug_exchange_all",
     "asm_profile_enable",
     "asm_profile_get",
 ]
@@ -155,6 +157,8 @@ def load_library():
     lib.asm_kernel_variant_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_synchronize.argtypes = [C.c_void_p]
     lib.asm_time_calls.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.asm_debug_external_exchange.argtypes = [C.c_void_p, C.c_int]
+    lib.asm_debug_exchange_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int]
     lib.asm_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.asm_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.asm_comm_unique_id.argtypes = [C.c_char_p]
@@ -246,6 +250,18 @@ def exchange_plan(params: AsmParams, add: bool):
     return [steps[i] for i in range(n.value)]
 
 
+def exchange_all(contexts, vectors, add=False):
+    """Testing aid (asm_debug_exchange_all): ghost exchange of vectors[r] of contexts[r], r = rank,
+    for all ranks of a partition living in this process."""
+    lib = load_library()
+    n = len(contexts)
+    cs = (C.c_void_p * n)(*[c.handle for c in contexts])
+    vs = (C.c_void_p * n)(*[v.ptr for v in vectors])
+    err = lib.asm_debug_exchange_all(cs, vs, n, 1 if add else 0)
+    if err:
+        raise RuntimeError(f"asm_debug_exchange_all failed ({err}): {lib.asm_last_error(contexts[0].handle).decode()}")
+
+
 class DeviceVector:
     """A device buffer in the library's box layout (initialize_dof_vector)."""
 
@@ -315,6 +331,10 @@ class Context:
     @property
     def n_dofs(self):
         return int(self.layout.n_global_dofs)
+
+    def external_exchange(self, on=True):
+        """Testing aid: vmult/step leave the ghost exchange to exchange_all()."""
+        self._check(self.lib.asm_debug_external_exchange(self.handle, 1 if on else 0))
 
     # -- operators (names follow the reference) -------------------------------
     def op_vmult(self, dst, src):

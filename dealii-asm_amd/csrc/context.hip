@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <memory>
@@ -48,6 +49,7 @@ struct asm_ctx
   ncclComm_t               comm       = nullptr;
   double *                 hbuf[4]    = {nullptr, nullptr, nullptr, nullptr}; // send lo/hi, recv lo/hi
   long long                hbuf_size  = 0;
+  bool                     external_exchange = false; // testing aid: ghosts are exchanged by asm_debug_exchange_all
   // optional per-kernel timing with HIP events on the context's stream
   bool                                           profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[2];
@@ -55,6 +57,17 @@ struct asm_ctx
   std::string              error;
 };
 
+#define HIP_TRY_CTX(c_, expr)                                                                      \
+  do                                                                                               \
+    {                                                                                              \
+      const hipError_t e_ = (expr);                                                                \
+      if (e_ != hipSuccess)                                                                        \
+        {                                                                                          \
+          (c_)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+          return ASM_ERR_DEVICE;                                                                   \
+        }                                                                                          \
+    }                                                                                              \
+  while (0)
 #define HIP_TRY(expr)                                                                              \
   do                                                                                               \
     {                                                                                              \
@@ -145,7 +158,7 @@ namespace
   int
   exchange(asm_ctx *ctx, double *v, const bool add)
   {
-    if (!multi_rank(ctx))
+    if (!multi_rank(ctx) || ctx->external_exchange)
       return ASM_OK;
     if (ctx->comm == nullptr)
       {
@@ -981,6 +994,72 @@ asm_debug_stamps(asm_ctx *ctx, unsigned long long out[32], int reset)
   return ASM_OK;
 }
 #endif
+
+// ---- testing aids: all ranks of a partition as contexts of ONE process on ONE device -------------
+// (a box with one GPU cannot run RCCL between two ranks; these two entry points let the tests run
+// the partitioned kernels, layouts and exchange plans on real device buffers all the same)
+int
+asm_debug_external_exchange(asm_ctx *ctx, int on)
+{
+  ctx->external_exchange = on != 0;
+  return ASM_OK;
+}
+
+// the ghost exchange (add == 0: update_ghost_values, add != 0: compress(add)) of vecs[r] of ctxs[r],
+// r = rank, for all ranks at once; device-to-device copies take the place of ncclSend/ncclRecv
+int
+asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
+{
+  for (int r = 0; r < n; ++r)
+    if (ctxs[r]->s.prm.rank != r || ctxs[r]->s.prm.world_size != n)
+      {
+        ctxs[r]->error = "asm_debug_exchange_all: ctxs[r] must be rank r of n";
+        return ASM_ERR_INVALID_VALUE;
+      }
+  std::vector<std::array<asm_exchange_step, 3>> steps(n);
+  int                                           n_steps = 0;
+  for (int r = 0; r < n; ++r)
+    n_steps = build_exchange_plan(ctxs[r]->s, add != 0, steps[r].data());
+  const auto count = [](const int32_t sz[3]) { return (long long)sz[0] * sz[1] * sz[2]; };
+  for (int i = 0; i < n_steps; ++i)
+    {
+      for (int r = 0; r < n; ++r)
+        for (int sd = 0; sd < 2; ++sd)
+          if (steps[r][i].peer[sd] >= 0 && count(steps[r][i].send_size[sd]) > 0)
+            vec_box(ctxs[r]->g, 0, vecs[r], ctxs[r]->hbuf[sd], steps[r][i].send_lo[sd], steps[r][i].send_size[sd], ctxs[r]->stream);
+      HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
+      for (int r = 0; r < n; ++r)
+        for (int sd = 0; sd < 2; ++sd)
+          {
+            const asm_exchange_step &st  = steps[r][i];
+            const long long          cnt = st.peer[sd] < 0 ? 0 : count(st.recv_size[sd]);
+            if (cnt == 0)
+              continue;
+            // my low neighbour sends me its high-side slab and vice versa
+            const asm_exchange_step &ps = steps[st.peer[sd]][i];
+            if (ps.peer[1 - sd] != r || count(ps.send_size[1 - sd]) != cnt)
+              {
+                ctxs[r]->error = "asm_debug_exchange_all: send and receive slabs do not match";
+                return ASM_ERR_INVALID_VALUE;
+              }
+            HIP_TRY_CTX(ctxs[r], hipMemcpy(ctxs[r]->hbuf[2 + sd], ctxs[st.peer[sd]]->hbuf[1 - sd], cnt * sizeof(double),
+                                           hipMemcpyDeviceToDevice));
+          }
+      for (int r = 0; r < n; ++r)
+        {
+          const asm_exchange_step &st = steps[r][i];
+          for (int sd = 0; sd < 2; ++sd)
+            if (st.peer[sd] >= 0 && count(st.recv_size[sd]) > 0)
+              vec_box(ctxs[r]->g, add ? 2 : 1, vecs[r], ctxs[r]->hbuf[2 + sd], st.recv_lo[sd], st.recv_size[sd], ctxs[r]->stream);
+          if (add)
+            for (int sd = 0; sd < 2; ++sd)
+              if (st.peer[sd] >= 0 && count(st.send_size[sd]) > 0)
+                vec_box(ctxs[r]->g, 3, vecs[r], nullptr, st.send_lo[sd], st.send_size[sd], ctxs[r]->stream);
+        }
+      HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
+    }
+  return ASM_OK;
+}
 
 int
 asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms)

@@ -439,40 +439,67 @@ namespace asmamd
         }
     }
 
-    // request the rows of cell layer cz
+    // request the rows of cell layer cz: GatherRequest::issue(n0, n1) emits the loads n0 .. n1-1, so
+    // that a caller can spread them over its arithmetic instead of blocking on a full queue
+    struct GatherRequest
+    {
+      const GatherPlan &gp;
+      const double *    src;
+      unsigned          lds_base; // LDS byte address of the wave's image (wave-uniform)
+      long long         Z[N1];
+      bool              on;
+
+      __device__ __forceinline__ GatherRequest(const DevGrid &g, const GatherPlan &plan, const double *s, const int cz,
+                                               double *Gw, const bool enabled)
+        : gp(plan)
+        , src(s)
+        , on(enabled)
+      {
+        lds_base =
+          __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)Gw);
+#pragma unroll
+        for (int k = 0; k < N1; ++k)
+          Z[k] = enabled ? plane_offset(g, P * cz + k) : 0;
+      }
+
+      // tie: a value the caller has just computed; it is passed through the asm statement so that
+      // the request keeps its place in the caller's instruction stream (pure arithmetic would
+      // otherwise sink below all requests)
+      template <int N0, int N1_>
+      __device__ __forceinline__ void
+      issue(double &tie) const
+      {
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 1)
+        return;
+#endif
+        if (!on)
+          return;
+#pragma unroll
+        for (int n = N0; n < N1_ && n < GN; ++n)
+          {
+            constexpr int   last = N1 - 1;
+            const int       k0 = gather_kmin(n), k1 = k0 < last ? k0 + 1 : last;
+            const long long zo = ((gp.khi >> n) & 1u) ? Z[k1] : Z[k0];
+            const double *  q  = src + zo + gp.off[n];
+            // Issued as an asm statement: hipcc would otherwise drain every pending vector memory
+            // operation (vmcnt(0)) at the next LDS access that might alias the destination, i.e. at
+            // the transposes right behind this request.  The asm form is invisible to the compiler's
+            // wait-count bookkeeping; gather_wait() is the explicit wait that covers it.
+            // M0 holds the wave-uniform LDS destination and is restored afterwards.
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep), "+v"(tie)
+                         : "v"(q), "s"(lds_base + n * 1024u)
+                         : "memory");
+          }
+      }
+    };
     __device__ __forceinline__ void
     gather_issue(const DevGrid &g, const GatherPlan &gp, const double *__restrict__ src, const int cz, double *Gw)
     {
-      // LDS byte address of the wave's image (wave-uniform)
-      const unsigned lds_base =
-        __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)Gw);
-      long long Z[N1];
-#pragma unroll
-      for (int k = 0; k < N1; ++k)
-        Z[k] = plane_offset(g, P * cz + k);
-#if defined(ASM_DMA_N)
-      constexpr int gn = ASM_DMA_N; // diagnostic build: fewer rows (results are wrong)
-#else
-      constexpr int gn = GN;
-#endif
-#pragma unroll
-      for (int n = 0; n < gn; ++n)
-        {
-          constexpr int   last = N1 - 1;
-          const int       k0 = gather_kmin(n), k1 = k0 < last ? k0 + 1 : last;
-          const long long zo = ((gp.khi >> n) & 1u) ? Z[k1] : Z[k0];
-          const double *  q  = src + zo + gp.off[n];
-          // Issued as an asm statement: hipcc would otherwise drain every pending vector memory
-          // operation (vmcnt(0)) at the next LDS access that might alias the destination, i.e. at
-          // the transposes right behind this request.  The asm form is invisible to the compiler's
-          // wait-count bookkeeping; gather_wait() is the explicit wait that covers it.
-          // M0 holds the wave-uniform LDS destination and is restored afterwards.
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep)
-                       : "v"(q), "s"(lds_base + n * 1024u)
-                       : "memory");
-        }
+      const GatherRequest rq(g, gp, src, cz, Gw, true);
+      double              tie = 0.;
+      rq.issue<0, GN>(tie);
     }
 
     // the staged image is complete and may be read / has been read and may be overwritten
@@ -615,6 +642,30 @@ namespace asmamd
               if (EpilogueOperands<MODE, NPL>::need_b)
                 ops.b[k * P + i] = a.x_old[off + i];
             }
+        }
+    }
+
+    // the same for one plane (callers spread the loads over their arithmetic)
+    template <int MODE, int NPL, int K>
+    __device__ __forceinline__ void
+    epilogue_prefetch_plane(const DevGrid &g, const CellLane &c, const TiledArgs &a, const int K0, EpilogueOperands<MODE, NPL> &ops,
+                            const bool enabled)
+    {
+      if (!EpilogueOperands<MODE, NPL>::need_a || !enabled)
+        return;
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 2)
+      for (int i = 0; i < P; ++i)
+        ops.a[K * P + i] = 1.0 + i;
+      return;
+#endif
+      const double *  pa  = (MODE == OP_RESIDUAL) ? a.b : a.x;
+      const long long off = plane_offset(g, K0 + K) + c.rowoff;
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        {
+          ops.a[K * P + i] = pa[off + i];
+          if (EpilogueOperands<MODE, NPL>::need_b)
+            ops.b[K * P + i] = a.x_old[off + i];
         }
     }
 
@@ -1134,54 +1185,78 @@ namespace asmamd
           // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
           // ---- layout A: x and y sweeps (even-odd form) ----------------------------------
           // rows: t2 = Kx u, u = Mx u
-#pragma unroll
-          for (int j = 0; j < N1; ++j)
-            {
-              const EvenOdd x = eo_split(u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);
-              EvenOdd       r;
-              eo_apply<false>(r, x, Km);
-              eo_join(r, t2[j * 5 + 0], t2[j * 5 + 1], t2[j * 5 + 2], t2[j * 5 + 3], t2[j * 5 + 4]);
-              eo_apply<false>(r, x, Mm);
-              eo_join(r, u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);
-            }
-          const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
-          // columns: t2 <- My (alpha t2) + Ky (beta u)  (needs Mz),  u <- My (gamma u)  (needs Kz)
-#pragma unroll
-          for (int f = 0; f < N1; ++f)
-            {
-              const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);
-              const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
-              EvenOdd       r;
-              eo_apply<false>(r, eo_scale(xa, alpha), Mm);
-              eo_apply<true>(r, eo_scale(xb, beta), Km);
-              eo_join(r, t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);
-              eo_apply<false>(r, eo_scale(xb, gamma), Mm);
-              eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
-            }
-          // ---- layout B: z sweeps ------------------------------------------------------
-          STAMP(2);
-          // the staged image has been consumed: request the next layer, and this layer's update operands
-#if !(defined(ASM_ABLATE) && (ASM_ABLATE & 1))
-          if (cz + 1 < Ze)
-            gather_issue(g, gp, a.src, cz + 1, Gw);
+          // the staged image has been consumed: the requests for the next layer's rows and for this
+          // layer's update operands are spread over the sweeps, a few per line
+          const GatherRequest rq(g, gp, a.src, cz + 1, Gw, cz + 1 < Ze);
+#if defined(ASM_TIE)
+#  define ASM_TIE_OR(x) x
+#else
+          double no_tie = 0.;
+#  define ASM_TIE_OR(x) no_tie
 #endif
           EpilogueOperands<MODE, P> ops;
-          if (cz >= Zb)
-            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
+          const bool                stored = true; // halo layers load them too (harmless): no branch around the loads
+#define ROW_X(j, n0, n1)                                                                                   \
+  {                                                                                                        \
+    const EvenOdd x = eo_split(u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);       \
+    EvenOdd       r;                                                                                       \
+    eo_apply<false>(r, x, Km);                                                                             \
+    eo_join(r, t2[j * 5 + 0], t2[j * 5 + 1], t2[j * 5 + 2], t2[j * 5 + 3], t2[j * 5 + 4]);                  \
+    eo_apply<false>(r, x, Mm);                                                                             \
+    eo_join(r, u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);                       \
+    rq.issue<n0, n1>(ASM_TIE_OR(u[j * 5 + 4]));                                                            \
+  }
+          ROW_X(0, 0, 1)
+          ROW_X(1, 1, 2)
+          ROW_X(2, 2, 3)
+          ROW_X(3, 3, 4)
+          ROW_X(4, 4, 5)
+#undef ROW_X
+          const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
+          // columns: t2 <- My (alpha t2) + Ky (beta u)  (needs Mz),  u <- My (gamma u)  (needs Kz)
+#define COL_Y(f, n0, n1)                                                                                              \
+  {                                                                                                                   \
+    const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);            \
+    const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                 \
+    EvenOdd       r;                                                                                                  \
+    eo_apply<false>(r, eo_scale(xa, alpha), Mm);                                                                      \
+    eo_apply<true>(r, eo_scale(xb, beta), Km);                                                                        \
+    eo_join(r, t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);                             \
+    eo_apply<false>(r, eo_scale(xb, gamma), Mm);                                                                      \
+    eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                                  \
+    rq.issue<n0, n1>(ASM_TIE_OR(u[4 * 5 + f]));                                                                       \
+  }
+          COL_Y(0, 5, 6)
+          COL_Y(1, 6, 7)
+          COL_Y(2, 7, 8)
+          COL_Y(3, 8, 9)
+          COL_Y(4, 9, 10)
+#undef COL_Y
+          // ---- layout B: z sweeps ------------------------------------------------------
+          STAMP(2);
           transpose5(t2, Tw, c);
+          epilogue_prefetch_plane<MODE, P, 0>(g, c, a, P * cz, ops, stored);
           transpose5(u, Tw, c);
           STAMP(3);
           // columns: u <- Kz u + Mz t2
-#pragma unroll
-          for (int f = 0; f < N1; ++f)
-            {
-              const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);
-              const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
-              EvenOdd       r;
-              eo_apply<false>(r, xa, Mm);
-              eo_apply<true>(r, xb, Km);
-              eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);
-            }
+#define COL_Z(f)                                                                                                      \
+  {                                                                                                                   \
+    const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);            \
+    const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                 \
+    EvenOdd       r;                                                                                                  \
+    eo_apply<false>(r, xa, Mm);                                                                                       \
+    eo_apply<true>(r, xb, Km);                                                                                        \
+    eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                                  \
+  }
+          COL_Z(0)
+          epilogue_prefetch_plane<MODE, P, 1>(g, c, a, P * cz, ops, stored);
+          COL_Z(1)
+          epilogue_prefetch_plane<MODE, P, 2>(g, c, a, P * cz, ops, stored);
+          COL_Z(2)
+          epilogue_prefetch_plane<MODE, P, 3>(g, c, a, P * cz, ops, stored);
+          COL_Z(3)
+          COL_Z(4)
+#undef COL_Z
           STAMP(6);
           merge_xz(c, u, carry);
           STAMP(7);

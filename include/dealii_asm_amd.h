@@ -254,6 +254,17 @@ int asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_m
  * elapsed milliseconds.  what: 0 op_vmult, 1 precond_vmult, 2 cheb_vmult, 3 cheb_step */
 int asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms);
 
+/* ----- testing aids ---------------------------------------------------------
+ * All ranks of a partition as contexts of ONE process on ONE device: RCCL cannot
+ * connect two ranks on the same GPU, so the tests use these two calls to run the
+ * partitioned kernels, vector layouts and exchange plans on real device buffers.
+ * asm_debug_external_exchange(ctx, 1): vmult/step no longer exchange ghosts
+ * themselves.  asm_debug_exchange_all: the exchange MFRunner::loop performs
+ * (include/matrix_free_internal.h:309-359; add == 0: update_ghost_values,
+ * add != 0: compress(add)) for vecs[r] of ctxs[r], r = rank = 0..n-1, at once. */
+int asm_debug_external_exchange(asm_ctx *ctx, int on);
+int asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add);
+
 #ifdef __cplusplus
 }
 #endif

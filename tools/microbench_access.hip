@@ -16,7 +16,7 @@ constexpr long long PLANE = (long long)PITCH * NP;
 
 template <int PATTERN, int DEPTH>
 __global__ void __launch_bounds__(512) sweep(double *__restrict__ dst, const double *__restrict__ b, const double *__restrict__ src,
-                                            int ntx, int nty, int zlen)
+                                            int ntx, int nty, int zlen, int zmod)
 {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int tx = blockIdx.x % ntx, ty = (blockIdx.x / ntx) % nty, zc = blockIdx.x / (ntx * nty);
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(512) sweep(double *__restrict__ dst, const dou
 #pragma unroll
           for (int k = 0; k < DEPTH; ++k)
             {
-              const long long off = (4ll * cz + k) * PLANE + rowoff;
+              const long long off = (4ll * (cz % zmod) + k) * PLANE + rowoff;
               x[k][0] = *(const dbl2 *)(b + off);
               x[k][1] = *(const dbl2 *)(b + off + 2);
               y[k][0] = *(const dbl2 *)(src + off);
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(512) sweep(double *__restrict__ dst, const dou
 #pragma unroll
               for (int k = 0; k < DEPTH; ++k)
                 {
-                  const long long off = (4ll * cz + k) * PLANE + rowoff;
+                  const long long off = (4ll * (cz % zmod) + k) * PLANE + rowoff;
                   *(dbl2 *)(dst + off)     = x[k][0] - y[k][0];
                   *(dbl2 *)(dst + off + 2) = x[k][1] - y[k][1];
                 }
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(512) sweep(double *__restrict__ dst, const dou
       for (int cz = 0; cz < zlen; ++cz)
         {
           dbl2 x[DEPTH][2], y[DEPTH][2];
-          const long long o = base + cz * per_wg_layer + w * (per_wg_layer / 8);
+          const long long o = base + (cz % zmod) * per_wg_layer + w * (per_wg_layer / 8);
 #pragma unroll
           for (int k = 0; k < DEPTH; ++k)
             {
@@ -93,9 +93,10 @@ int main()
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int ntx = 8, nty = 12;
+  for (int zmod : {1000, 2, 1})
   for (int pattern = 0; pattern < 2; ++pattern)
-    for (int wgs_per_cu : {1, 2, 4})
-      for (int nzc : {5, 10})
+    for (int wgs_per_cu : {1, 2})
+      for (int nzc : {5})
         {
           const int    zlen = 80 / nzc;
           const size_t lds  = wgs_per_cu == 1 ? 100 * 1024 : (wgs_per_cu == 2 ? 60 * 1024 : 30 * 1024);
@@ -105,7 +106,7 @@ int main()
           for (int rep = 0; rep < 5; ++rep)
             {
               hipEventRecord(e0);
-              hipLaunchKernelGGL(k, dim3(ntx * nty * nzc), dim3(512), lds, 0, dst, b, src, ntx, nty, zlen);
+              hipLaunchKernelGGL(k, dim3(ntx * nty * nzc), dim3(512), lds, 0, dst, b, src, ntx, nty, zlen, zmod);
               hipEventRecord(e1);
               hipEventSynchronize(e1);
               float ms;
@@ -114,7 +115,7 @@ int main()
             }
           // bytes: pattern 0 moves 24 B per owned DoF (80^3 cells x 64); pattern 1 per lane
           const double bytes = pattern == 0 ? 24.0 * 80 * 80 * 80 * 64 : 24.0 * (double)ntx * nty * nzc * zlen * 512 * 16;
-          printf("pattern=%s wg/CU<=%d chunks=%d: %.3f ms  %.2f TB/s\n", pattern == 0 ? "tile " : "linear", wgs_per_cu, nzc, best,
+          printf("zmod=%d pattern=%s wg/CU<=%d chunks=%d: %.3f ms  %.2f TB/s\n", zmod, pattern == 0 ? "tile " : "linear", wgs_per_cu, nzc, best,
                  bytes / best / 1e9);
         }
   return 0;
