@@ -25,6 +25,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace asmamd
 {
   bool
@@ -54,9 +57,11 @@ namespace asmamd
     constexpr int YS  = P * N1;   // doubles per y-merge slot: planes 0..3 x columns 0..4
 
     constexpr int TBUF      = 64 * N1;           // one transpose buffer (all 64 lanes write, no predicate)
-    constexpr int LDS_T     = TY * 2 * TBUF;     // two per wave
+    constexpr int LDS_T     = TY * TBUF;         // one per wave
     constexpr int LDS_Y     = 2 * TY * WX * YS;  // y-merge slots, double-buffered
     constexpr int LDS_TAB   = 16 * EIG;          // eigen tables
+    constexpr int INV_MAX   = 3;                 // instances per direction up to which ...
+    constexpr int LDS_INV   = INV_MAX * INV_MAX * N1 * NE; // ... the reciprocal eigenvalue sums of a layer fit
     // staged source rows of one wave and layer: 25 rows (5 planes x 5 DoF rows) of 25 16-byte chunks
     constexpr int GCH       = (PX_DOFS + 1) / 2; // chunks per row
     constexpr int GROW      = 2 * GCH;           // doubles per staged row (49 DoFs + 1)
@@ -64,7 +69,7 @@ namespace asmamd
     constexpr int GBUF      = GN * 128;          // doubles per wave
     constexpr int LDS_G     = TY * GBUF;
     constexpr int LDS_FLAG  = TY;                // 2 x TY ints: y-merge hand-off counters
-    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_G + LDS_TAB + LDS_FLAG;
+    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_G + LDS_TAB + LDS_INV + LDS_FLAG;
 
 #ifdef ASM_STAMP
     // diagnostic build: cycles (s_memtime) an interior wave spends between the STAMP marks
@@ -550,7 +555,7 @@ namespace asmamd
     // 5-lane transpose: lane `sub` of a cell holds v[s*5 + f]; afterwards it holds
     // v'[s*5 + f] = (value v[sub*5 + f] of the cell's lane s), i.e. the lane index and the
     // slow register index change places (layout A <-> B).  One fast index f per round
-    // through the wave-private buffer (2 x 320 doubles).
+    // through the wave-private buffer (320 doubles).
     // The LDS executes the instructions of one wave in order, so a read sees the partner lanes'
     // earlier writes and a later write cannot overtake an earlier read of the same words: no
     // s_waitcnt is needed between the rounds, only the compiler must not reorder the accesses.
@@ -569,7 +574,7 @@ namespace asmamd
 #pragma unroll
       for (int f = 0; f < N1; ++f)
         {
-          double *buf = Tw + (f & 1) * TBUF;
+          double *buf = Tw;
 #pragma unroll
           for (int s = 0; s < N1; ++s)
             buf[c.lane * N1 + s] = v[s * 5 + f];
@@ -867,13 +872,14 @@ namespace asmamd
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
-      double *Tw = S_T + c.w * (2 * TBUF);
+      double *Tw = S_T + c.w * TBUF;
       double *Gw = S_G + c.w * GBUF;
       GatherPlan gp;
       gather_plan_setup(g, X0, Y0, gp);
 
       YSync ys;
-      ys.prod = (volatile int *)(S_tab + LDS_TAB);
+      double *S_inv = S_tab + LDS_TAB;
+      ys.prod       = (volatile int *)(S_inv + LDS_INV);
       ys.cons = ys.prod + TY;
       ys.seq  = 0;
       if (threadIdx.x < 2 * TY)
@@ -924,6 +930,8 @@ namespace asmamd
           for (int i = 0; i < N1; ++i)
             wpost_x[i] = f.w_post[0][(cxs + 1) * N1 + i];
         }
+      const bool inv_lds   = TENSOR && f.inv_table != nullptr && f.n_inst <= INV_MAX;
+      int        iz_cached = -1;
       for (int cz = z_first; cz < Ze; ++cz)
         {
           STAMP(0);
@@ -947,6 +955,17 @@ namespace asmamd
           // tensor-product meshes: the y and z matrices depend on the cell row / layer only
           // (taken from the row / layer index, not from a lane: lane 0 may hold a cell that does not exist)
           const int iz_u = TENSOR ? uniform_load(f.inst[2], cz + 1) : 0;
+          // reciprocal eigenvalue sums of all (ix, iy) pairs of this layer's z instance: kept in LDS,
+          // refilled when the z instance changes (first / last layers of a block)
+          if (inv_lds && iz_u != iz_cached)
+            {
+              __syncthreads(); // the previous tables are no longer read
+              const int nn = f.n_inst * f.n_inst * (N1 * NE);
+              for (int e = threadIdx.x; e < nn; e += NT)
+                S_inv[e] = f.inv_table[(long long)iz_u * nn + e];
+              __syncthreads();
+              iz_cached = iz_u;
+            }
           const UniformMatrix Uy(f.eig + (long long)__builtin_amdgcn_readfirstlane(iy_u) * EIG),
             Uz(f.eig + (long long)__builtin_amdgcn_readfirstlane(iz_u) * EIG);
           // the x matrix is wave-uniform too unless the cell row touches a boundary column
@@ -1015,9 +1034,18 @@ namespace asmamd
             }
 #if defined(ASM_ABLATE) && (ASM_ABLATE & 128)
           if (false)
+            {
+            }
 #else
-          if (f.inv_table != nullptr)
+          if (inv_lds)
+            {
+              const double *inv = S_inv + (iy * f.n_inst + ix) * (N1 * NE) + c.sub * NE;
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                v[e] *= inv[e];
+            }
 #endif
+          else if (f.inv_table != nullptr)
             {
               // table [iz][iy][ix][c][b][a]
               const double *inv = f.inv_table + (long long)((iz * f.n_inst + iy) * f.n_inst + ix) * (N1 * NE) + c.sub * NE;
@@ -1140,13 +1168,13 @@ namespace asmamd
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
-      double *Tw = S_T + c.w * (2 * TBUF);
+      double *Tw = S_T + c.w * TBUF;
       double *Gw = S_G + c.w * GBUF;
       GatherPlan gp;
       gather_plan_setup(g, X0, Y0, gp);
 
       YSync ys;
-      ys.prod = (volatile int *)(S_G + LDS_G + LDS_TAB);
+      ys.prod = (volatile int *)(S_G + LDS_G + LDS_TAB + LDS_INV);
       ys.cons = ys.prod + TY;
       ys.seq  = 0;
       if (threadIdx.x < 2 * TY)
@@ -1290,9 +1318,35 @@ namespace asmamd
       // the last owned plane nc*p of a non-wrapped direction is produced by the tile
       // that holds cell nc-1, no extra tile needed
       const int tiles = tl.ntx * tl.nty;
-      // one workgroup per CU: aim at ~2 x 256 workgroups, chunks of >= 4 layers
-      int best = std::max(1, std::min(512 / tiles, g.nc[2] / 4));
-      best     = std::min(best, g.nc[2]);
+      // One workgroup per CU at a time.  Workgroups run in rounds of n_cu; a chunk of zlen layers
+      // costs zlen + 1 layer times (halo layer) plus about half a layer of start-up: take the
+      // number of chunks with the smallest  rounds x (zlen + 1.5).
+      static int n_cu = 0;
+      if (n_cu == 0)
+        {
+          int dev = 0;
+          hipDeviceProp_t prop;
+          if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+          if (n_cu <= 0)
+            n_cu = 256;
+        }
+      int    best      = 1;
+      double best_cost = 1e300;
+      for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
+        {
+          const int    zlen   = (g.nc[2] + nzc - 1) / nzc;
+          const int    chunks = (g.nc[2] + zlen - 1) / zlen;
+          const int    rounds = (tiles * chunks + n_cu - 1) / n_cu;
+          const double cost   = rounds * (zlen + 1.5);
+          if (cost < best_cost - 1e-9)
+            {
+              best_cost = cost;
+              best      = nzc;
+            }
+        }
+      if (const char *e = std::getenv("ASM_TILED_ZCHUNKS")) // experiments only
+        best = std::max(1, std::min(std::atoi(e), g.nc[2]));
       tl.zlen = (g.nc[2] + best - 1) / best;
       tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
       return tl;
