@@ -75,3 +75,21 @@ def test_generic_partitioned(what, world, n_cells):
 def test_tiled_partitioned_weightings(weighting):
     pkg = load_package()
     assert run_partitioned(pkg, 4, (4, 6, 6), "dirichlet", "tiled", "precond", weighting) < TOL
+
+
+def test_tiled_results_are_bitwise_reproducible():
+    """No atomics and a fixed summation order in the tiled kernels."""
+    pkg = load_package()
+    ctx = pkg.Context(degree=4, n_cells=(13, 9, 7), boundary="dirichlet", precond="FDM", n_overlap=1, weighting="post", cheb_degree=3)
+    assert ctx.kernel_variant() == "tiled"
+    ctx.set_eigenvalue(1.7)
+    rng = np.random.default_rng(3)
+    b = ctx.vector(rng.standard_normal(ctx.n_owned))
+    outs = []
+    for _ in range(3):
+        x = ctx.vector(np.zeros(ctx.n_owned))
+        ctx.cheb_vmult(x, b)
+        ctx.cheb_step(x, b)
+        outs.append(x.get())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    ctx.close()

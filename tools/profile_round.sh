@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/profile_round.sh  -> everything under gpurun_out/prof_round/
+set -e
+R=$PWD
+O=$R/gpurun_out/prof_round
+mkdir -p $O
+python bench.py > $O/bench_default.json
+for w in "--workload cart_periodic" "--workload kershaw" "--degree 3" "--cells 128 128 96"; do
+  python bench.py --no-cpu-baseline $w >> $O/bench_others.jsonl
+done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/kt.log 2>&1
+cd $R
+tools/pmc.sh "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_traffic.txt
+find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
