@@ -400,6 +400,24 @@ namespace asmamd
       return g.store_index_near(2, K) * g.stride[2];
     }
 
+    // storage offsets of the 5 DoF planes P cz .. P cz + 4 of cell layer cz (wave-uniform): one
+    // wrap decision per layer for plane 0 (planes 1..3 follow it) and one for plane 4
+    struct LayerPlanes
+    {
+      long long z[N1];
+    };
+    __device__ __forceinline__ LayerPlanes
+    layer_planes(const DevGrid &g, const int cz)
+    {
+      LayerPlanes     lp;
+      const long long s0 = g.store_index_near(2, P * cz);
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        lp.z[k] = (s0 + k) * g.stride[2];
+      lp.z[P] = plane_offset(g, P * cz + P);
+      return lp;
+    }
+
     // ---------------------------------------------------------------------------
     // Source staging.  A wave needs, per layer, 5 planes x 5 DoF rows of 49 consecutive DoFs.
     // They are copied global -> LDS by 10 direct-to-LDS loads (every lane one 16-byte chunk,
@@ -464,7 +482,14 @@ namespace asmamd
           __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)Gw);
 #pragma unroll
         for (int k = 0; k < N1; ++k)
-          Z[k] = enabled ? plane_offset(g, P * cz + k) : 0;
+          Z[k] = 0;
+        if (enabled)
+          {
+            const LayerPlanes lp = layer_planes(g, cz);
+#pragma unroll
+            for (int k = 0; k < N1; ++k)
+              Z[k] = lp.z[k];
+          }
       }
 
       // tie: a value the caller has just computed; it is passed through the asm statement so that
@@ -623,7 +648,7 @@ namespace asmamd
     // operands of the fused update of planes K0 .. K0 + NPL - 1: issued early, used after the merge
     template <int MODE, int NPL>
     __device__ __forceinline__ void
-    epilogue_prefetch(const DevGrid &g, const CellLane &c, const TiledArgs &a, const int K0, EpilogueOperands<MODE, NPL> &ops)
+    epilogue_prefetch(const LayerPlanes &lp, const CellLane &c, const TiledArgs &a, EpilogueOperands<MODE, NPL> &ops)
     {
       if (!EpilogueOperands<MODE, NPL>::need_a)
         return;
@@ -636,7 +661,7 @@ namespace asmamd
 #pragma unroll
       for (int k = 0; k < NPL; ++k)
         {
-          const long long off = plane_offset(g, K0 + k) + c.rowoff;
+          const long long off = lp.z[k] + c.rowoff;
 #if defined(ASM_OPS_PRED)
           if (c.own_row)
 #endif
@@ -653,7 +678,7 @@ namespace asmamd
     // the same for one plane (callers spread the loads over their arithmetic)
     template <int MODE, int NPL, int K>
     __device__ __forceinline__ void
-    epilogue_prefetch_plane(const DevGrid &g, const CellLane &c, const TiledArgs &a, const int K0, EpilogueOperands<MODE, NPL> &ops,
+    epilogue_prefetch_plane(const LayerPlanes &lp, const CellLane &c, const TiledArgs &a, EpilogueOperands<MODE, NPL> &ops,
                             const bool enabled)
     {
       if (!EpilogueOperands<MODE, NPL>::need_a || !enabled)
@@ -664,7 +689,7 @@ namespace asmamd
       return;
 #endif
       const double *  pa  = (MODE == OP_RESIDUAL) ? a.b : a.x;
-      const long long off = plane_offset(g, K0 + K) + c.rowoff;
+      const long long off = lp.z[K] + c.rowoff;
 #pragma unroll
       for (int i = 0; i < P; ++i)
         {
@@ -734,8 +759,8 @@ namespace asmamd
 
     template <int MODE, int NPL>
     __device__ __forceinline__ void
-    merge_y_and_store(const DevGrid &g, const CellLane &c, const TiledArgs &a, double *__restrict__ Sy, double (&o)[NE],
-                      const int K0, const EpilogueOperands<MODE, NPL> &ops, YSync &ys STAMP_PARAM)
+    merge_y_and_store(const DevGrid &g, const LayerPlanes &lp, const CellLane &c, const TiledArgs &a, double *__restrict__ Sy,
+                      double (&o)[NE], const int K0, const EpilogueOperands<MODE, NPL> &ops, YSync &ys STAMP_PARAM)
     {
 #if !(defined(ASM_ABLATE) && (ASM_ABLATE & 8))
       // ---- y: row 4 -> row 0 of the cell above
@@ -795,7 +820,7 @@ namespace asmamd
 #pragma unroll
           for (int k = 0; k < NPL; ++k)
             {
-              const long long off = plane_offset(g, K0 + k) + c.rowoff;
+              const long long off = lp.z[k] + c.rowoff;
               double          rr[P];
 #pragma unroll
               for (int i = 0; i < P; ++i)
@@ -821,7 +846,7 @@ namespace asmamd
 #pragma unroll
               for (int k = 0; k < NPL; ++k)
                 {
-                  const long long off = plane_offset(g, K0 + k) + c.rowoff + P;
+                  const long long off = lp.z[k] + c.rowoff + P;
                   const bool      con = yd || ((zdm >> k) & 1u) || ((c.xd >> P) & 1u);
                   double          t   = o[k * 5 + P];
                   if (con)
@@ -839,7 +864,7 @@ namespace asmamd
                   const unsigned cm = (yd || ((zdm >> k) & 1u)) ? 0xfu : (c.xd & 0xfu);
                   if (cm != 0u)
                     {
-                      const long long off = plane_offset(g, K0 + k) + c.rowoff;
+                      const long long off = lp.z[k] + c.rowoff;
 #pragma unroll
                       for (int i = 0; i < P; ++i)
                         if ((cm >> i) & 1u)
@@ -935,6 +960,7 @@ namespace asmamd
       for (int cz = z_first; cz < Ze; ++cz)
         {
           STAMP(0);
+          const LayerPlanes lp = layer_planes(g, cz);
           staged_read<true, false>(g, c, Gw, cz, v);
           gather_release();
           int ix = ix_t, iy = iy_t, iz = 0;
@@ -1082,7 +1108,7 @@ namespace asmamd
 #endif
           EpilogueOperands<MODE, P> ops;
           if (cz >= Zb)
-            epilogue_prefetch<MODE, P>(g, c, a, P * cz, ops);
+            epilogue_prefetch<MODE, P>(lp, c, a, ops);
           if (sym_y)
             sweep_slow_eo<false>(v, Uy.fresh());
           else if (TENSOR)
@@ -1125,7 +1151,7 @@ namespace asmamd
           STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops, ys STAMP_ARG);
+              merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops, ys STAMP_ARG);
               par ^= 1;
             }
           else
@@ -1138,11 +1164,12 @@ namespace asmamd
         {
           // top plane of the block (physical boundary): what the last layer left in the carry
           EpilogueOperands<MODE, 1> ops;
-          epilogue_prefetch<MODE, 1>(g, c, a, P * g.nc[2], ops);
+          const LayerPlanes         lp = layer_planes(g, g.nc[2]);
+          epilogue_prefetch<MODE, 1>(lp, c, a, ops);
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             v[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops, ys STAMP_ARG);
+          merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops, ys STAMP_ARG);
         }
     }
 
@@ -1206,6 +1233,7 @@ namespace asmamd
       for (int cz = z_first; cz < Ze; ++cz)
         {
           STAMP(0);
+          const LayerPlanes lp = layer_planes(g, cz);
           staged_read<false, true>(g, c, Gw, cz, u);
           gather_release();
           const double hz = uniform_load(op.h[2], cz + 1);
@@ -1263,7 +1291,7 @@ namespace asmamd
           // ---- layout B: z sweeps ------------------------------------------------------
           STAMP(2);
           transpose5(t2, Tw, c);
-          epilogue_prefetch_plane<MODE, P, 0>(g, c, a, P * cz, ops, stored);
+          epilogue_prefetch_plane<MODE, P, 0>(lp, c, a, ops, stored);
           transpose5(u, Tw, c);
           STAMP(3);
           // columns: u <- Kz u + Mz t2
@@ -1277,11 +1305,11 @@ namespace asmamd
     eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                                  \
   }
           COL_Z(0)
-          epilogue_prefetch_plane<MODE, P, 1>(g, c, a, P * cz, ops, stored);
+          epilogue_prefetch_plane<MODE, P, 1>(lp, c, a, ops, stored);
           COL_Z(1)
-          epilogue_prefetch_plane<MODE, P, 2>(g, c, a, P * cz, ops, stored);
+          epilogue_prefetch_plane<MODE, P, 2>(lp, c, a, ops, stored);
           COL_Z(2)
-          epilogue_prefetch_plane<MODE, P, 3>(g, c, a, P * cz, ops, stored);
+          epilogue_prefetch_plane<MODE, P, 3>(lp, c, a, ops, stored);
           COL_Z(3)
           COL_Z(4)
 #undef COL_Z
@@ -1290,7 +1318,7 @@ namespace asmamd
           STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops, ys STAMP_ARG);
+              merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops, ys STAMP_ARG);
               par ^= 1;
             }
           else
@@ -1301,11 +1329,12 @@ namespace asmamd
       if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
         {
           EpilogueOperands<MODE, 1> ops;
-          epilogue_prefetch<MODE, 1>(g, c, a, P * g.nc[2], ops);
+          const LayerPlanes         lp = layer_planes(g, g.nc[2]);
+          epilogue_prefetch<MODE, 1>(lp, c, a, ops);
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             u[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops, ys STAMP_ARG);
+          merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops, ys STAMP_ARG);
         }
     }
 
