@@ -560,6 +560,10 @@ asm_create(const asm_params *p, asm_ctx **out)
   UP(ctx->basis->K_ref, &op.K_ref);
   UP(ctx->basis->M_eo, &op.M_eo);
   UP(ctx->basis->K_eo, &op.K_eo);
+  if (ctx->basis->n1 == 5)
+    ctx->basis->diagonalise();
+  UP(ctx->basis->F_ref, &op.F_ref);
+  UP(ctx->basis->lam_ref, &op.lam_ref);
   // FDM data
   DevFdm &f = ctx->f;
   std::memset(&f, 0, sizeof(f));

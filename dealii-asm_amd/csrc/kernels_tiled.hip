@@ -189,9 +189,9 @@ namespace asmamd
         line5<FWD>(v[0 * 5 + f], v[1 * 5 + f], v[2 * 5 + f], v[3 * 5 + f], v[4 * 5 + f], q);
     }
 
-    // ---- even-odd forms (13 products + 8 sums per line instead of 25 products) --------------
-    // (1) matrix with columns 0..2 even and columns 3, 4 odd vectors (parity-sorted eigenvectors,
-    //     numerics.h: sort_eigenvectors_by_parity); same meaning of FWD as line5
+    // ---- even-odd form (13 products + 4 sums per line instead of 25 products) for a matrix with
+    // columns 0..2 even and columns 3, 4 odd vectors (parity-sorted eigenvectors, numerics.h:
+    // sort_eigenvectors_by_parity); same meaning of FWD as line5
     template <bool FWD, typename Q>
     __device__ __forceinline__ void
     line5_eo(double &u0, double &u1, double &u2, double &u3, double &u4, const Q &q)
@@ -239,49 +239,6 @@ namespace asmamd
         line5_eo<FWD>(v[0 * 5 + f], v[1 * 5 + f], v[2 * 5 + f], v[3 * 5 + f], v[4 * 5 + f], q);
     }
 
-    // (2) symmetric matrix invariant under (i, j) -> (4-i, 4-j), given by its 9 even-odd
-    //     coefficients c (numerics.h: even_odd_coefficients).  A line is split into its even part
-    //     (e0, e1, m) and odd part (o0, o1); the parts of several products can be accumulated
-    //     before the outputs are recombined.
-    struct EvenOdd
-    {
-      double e0, e1, m, o0, o1;
-    };
-    __device__ __forceinline__ EvenOdd
-    eo_split(const double u0, const double u1, const double u2, const double u3, const double u4)
-    {
-      return {u0 + u4, u1 + u3, u2, u0 - u4, u1 - u3};
-    }
-    // r = A x (ACC = false) or r += A x, both in split form (S0, S1, y2, D0, D1 stored as e0, e1, m, o0, o1)
-    template <bool ACC, typename C>
-    __device__ __forceinline__ void
-    eo_apply(EvenOdd &r, const EvenOdd &x, const C &c)
-    {
-#if defined(ASM_ABLATE) && (ASM_ABLATE & 32)
-      r = x;
-      return; // diagnostic build (results are wrong)
-#endif
-      r.e0 = fma(c[2], x.m, fma(c[1], x.e1, ACC ? fma(c[0], x.e0, r.e0) : c[0] * x.e0));
-      r.e1 = fma(c[4], x.m, fma(c[3], x.e1, ACC ? fma(c[1], x.e0, r.e1) : c[1] * x.e0));
-      r.m  = fma(c[5], x.m, fma(c[4], x.e1, ACC ? fma(c[2], x.e0, r.m) : c[2] * x.e0));
-      r.o0 = fma(c[7], x.o1, ACC ? fma(c[6], x.o0, r.o0) : c[6] * x.o0);
-      r.o1 = fma(c[8], x.o1, ACC ? fma(c[7], x.o0, r.o1) : c[7] * x.o0);
-    }
-    __device__ __forceinline__ void
-    eo_join(const EvenOdd &r, double &u0, double &u1, double &u2, double &u3, double &u4)
-    {
-      u0 = r.e0 + r.o0;
-      u4 = r.e0 - r.o0;
-      u1 = r.e1 + r.o1;
-      u3 = r.e1 - r.o1;
-      u2 = r.m;
-    }
-    __device__ __forceinline__ EvenOdd
-    eo_scale(const EvenOdd &x, const double f)
-    {
-      return {x.e0 * f, x.e1 * f, x.m * f, x.o0 * f, x.o1 * f};
-    }
-
     // a wave-uniform 5x5 matrix in global memory: the loads become scalar loads and the
     // entries scalar operands of the FMAs, so they cost no vector registers
     struct UniformMatrix
@@ -301,16 +258,6 @@ namespace asmamd
         asm volatile("" : "+s"(r.p));
         return r;
       }
-    };
-
-    // the 9 even-odd coefficients of a reference matrix: two such tables stay resident in scalar registers
-    struct UniformCoefficients
-    {
-      const __attribute__((address_space(4))) double *p;
-      __device__ __forceinline__ explicit UniformCoefficients(const double *q)
-        : p((const __attribute__((address_space(4))) double *)q)
-      {}
-      __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
     };
 
     // read-only table entry at a wave-uniform index: a scalar load (s_load), so that it does not
@@ -750,7 +697,7 @@ namespace asmamd
       volatile int *prod, *cons;
       int           seq; // running number of the merge (same in every wave)
     };
-    __device__ __forceinline__ void
+    [[maybe_unused]] __device__ __forceinline__ void
     spin_until(volatile int *flag, const int n)
     {
       while (__builtin_amdgcn_readfirstlane(*flag) < n)
@@ -1174,11 +1121,15 @@ namespace asmamd
     }
 
     // ---------------------------------------------------------------------------
-    // Laplace sweep on Cartesian cells.  For a box cell the sum-factorised
-    // evaluate/integrate pair with exact Gauss quadrature (include/operator.h:866-875)
-    // equals the Kronecker sum  hy hz/hx Mz My Kx + hx hz/hy Mz Ky Mx + hx hy/hz Kz My Mx
-    // of the 1-D reference mass/stiffness matrices, which needs 7 one-dimensional
-    // sweeps instead of 12 and no quadrature-point data.
+    // Laplace sweep on Cartesian cells.  For a box cell the sum-factorised evaluate / integrate
+    // pair with exact Gauss quadrature (include/operator.h:866-875) equals the Kronecker sum
+    //   hy hz/hx Mz My Kx + hx hz/hy Mz Ky Mx + hx hy/hz Kz My Mx
+    // of the 1-D reference mass / stiffness matrices.  With their simultaneous diagonalisation
+    // M = F F^T, K = F diag(lam) F^T (numerics.h: Basis1D::diagonalise) the cell matrix is
+    //   (F x F x F) diag(hy hz/hx lam_a + hx hz/hy lam_b + hx hy/hz lam_c) (F x F x F)^T :
+    // 6 one-dimensional sweeps with ONE wave-uniform matrix whose columns are even / odd vectors
+    // (even-odd form: 17 operations per line), a diagonal scaling in between, no quadrature-point
+    // data, and the same register choreography as the FDM sweep.
     // ---------------------------------------------------------------------------
     template <int MODE>
     __global__ void __launch_bounds__(NT, TY / 4)
@@ -1207,13 +1158,10 @@ namespace asmamd
       if (threadIdx.x < 2 * TY)
         ys.prod[threadIdx.x] = -1;
       __syncthreads();
-#if defined(ASM_SKEW)
-      for (int i = 0; i < (int)(threadIdx.x >> 6) * ASM_SKEW; ++i)
-        __builtin_amdgcn_s_sleep(16);
-#endif
 
-      // even-odd coefficients of the reference matrices: wave-uniform scalar operands
-      const UniformCoefficients Mm(op.M_eo), Km(op.K_eo);
+      // F (row i, column a) and the eigenvalues: wave-uniform scalar operands
+      const UniformMatrix Fm(op.F_ref);
+      const UniformMatrix Lm(op.lam_ref);
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
@@ -1223,8 +1171,9 @@ namespace asmamd
           hx = op.h[0][c.cx + 1];
           hy = op.h[1][c.cy + 1];
         }
+      const double lam_sub = op.lam_ref[c.sub]; // eigenvalue of the lane's own index in the middle layout
 
-      double u[NE]; // layout A on entry of a layer, layout B at its end
+      double u[NE]; // the lane's rows (layout B)
       double carry[N1] = {0., 0., 0., 0., 0.};
       int    par       = 0;
       gather_issue(g, gp, a.src, z_first, Gw);
@@ -1234,85 +1183,45 @@ namespace asmamd
         {
           STAMP(0);
           const LayerPlanes lp = layer_planes(g, cz);
-          staged_read<false, true>(g, c, Gw, cz, u);
+          staged_read<true, true>(g, c, Gw, cz, u);
           gather_release();
-          const double hz = uniform_load(op.h[2], cz + 1);
-          double       t2[NE];
-          // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
-          // ---- layout A: x and y sweeps (even-odd form) ----------------------------------
-          // rows: t2 = Kx u, u = Mx u
-          // the staged image has been consumed: the requests for the next layer's rows and for this
-          // layer's update operands are spread over the sweeps, a few per line
-          const GatherRequest rq(g, gp, a.src, cz + 1, Gw, cz + 1 < Ze);
-#if defined(ASM_TIE)
-#  define ASM_TIE_OR(x) x
-#else
-          double no_tie = 0.;
-#  define ASM_TIE_OR(x) no_tie
-#endif
-          EpilogueOperands<MODE, P> ops;
-          const bool                stored = true; // halo layers load them too (harmless): no branch around the loads
-#define ROW_X(j, n0, n1)                                                                                   \
-  {                                                                                                        \
-    const EvenOdd x = eo_split(u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);       \
-    EvenOdd       r;                                                                                       \
-    eo_apply<false>(r, x, Km);                                                                             \
-    eo_join(r, t2[j * 5 + 0], t2[j * 5 + 1], t2[j * 5 + 2], t2[j * 5 + 3], t2[j * 5 + 4]);                  \
-    eo_apply<false>(r, x, Mm);                                                                             \
-    eo_join(r, u[j * 5 + 0], u[j * 5 + 1], u[j * 5 + 2], u[j * 5 + 3], u[j * 5 + 4]);                       \
-    rq.issue<n0, n1>(ASM_TIE_OR(u[j * 5 + 4]));                                                            \
-  }
-          ROW_X(0, 0, 1)
-          ROW_X(1, 1, 2)
-          ROW_X(2, 2, 3)
-          ROW_X(3, 3, 4)
-          ROW_X(4, 4, 5)
-#undef ROW_X
+          const double hz    = uniform_load(op.h[2], cz + 1);
           const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
-          // columns: t2 <- My (alpha t2) + Ky (beta u)  (needs Mz),  u <- My (gamma u)  (needs Kz)
-#define COL_Y(f, n0, n1)                                                                                              \
-  {                                                                                                                   \
-    const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);            \
-    const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                 \
-    EvenOdd       r;                                                                                                  \
-    eo_apply<false>(r, eo_scale(xa, alpha), Mm);                                                                      \
-    eo_apply<true>(r, eo_scale(xb, beta), Km);                                                                        \
-    eo_join(r, t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);                             \
-    eo_apply<false>(r, eo_scale(xb, gamma), Mm);                                                                      \
-    eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                                  \
-    rq.issue<n0, n1>(ASM_TIE_OR(u[4 * 5 + f]));                                                                       \
-  }
-          COL_Y(0, 5, 6)
-          COL_Y(1, 6, 7)
-          COL_Y(2, 7, 8)
-          COL_Y(3, 8, 9)
-          COL_Y(4, 9, 10)
-#undef COL_Y
-          // ---- layout B: z sweeps ------------------------------------------------------
+          // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
+          // ---- layout B: lane = (cell, y row j), u[k*5 + i]; x and z forward sweeps -------
+          STAMP(1);
+          sweep_fast_eo<true>(u, Fm);
+          sweep_slow_eo<true>(u, Fm);
+          // the staged image has been consumed: request the next layer's rows
+          const GatherRequest rq(g, gp, a.src, cz + 1, Gw, cz + 1 < Ze);
+          double              no_tie = 0.;
+          rq.issue<0, GN>(no_tie);
+          // ---- layout A: lane = (cell, z index c), u[b*5 + a]; y sweeps + scaling ---------
           STAMP(2);
-          transpose5(t2, Tw, c);
-          epilogue_prefetch_plane<MODE, P, 0>(lp, c, a, ops, stored);
           transpose5(u, Tw, c);
           STAMP(3);
-          // columns: u <- Kz u + Mz t2
-#define COL_Z(f)                                                                                                      \
-  {                                                                                                                   \
-    const EvenOdd xa = eo_split(t2[0 * 5 + f], t2[1 * 5 + f], t2[2 * 5 + f], t2[3 * 5 + f], t2[4 * 5 + f]);            \
-    const EvenOdd xb = eo_split(u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                 \
-    EvenOdd       r;                                                                                                  \
-    eo_apply<false>(r, xa, Mm);                                                                                       \
-    eo_apply<true>(r, xb, Km);                                                                                        \
-    eo_join(r, u[0 * 5 + f], u[1 * 5 + f], u[2 * 5 + f], u[3 * 5 + f], u[4 * 5 + f]);                                  \
-  }
-          COL_Z(0)
-          epilogue_prefetch_plane<MODE, P, 1>(lp, c, a, ops, stored);
-          COL_Z(1)
-          epilogue_prefetch_plane<MODE, P, 2>(lp, c, a, ops, stored);
-          COL_Z(2)
-          epilogue_prefetch_plane<MODE, P, 3>(lp, c, a, ops, stored);
-          COL_Z(3)
-          COL_Z(4)
-#undef COL_Z
+          sweep_slow_eo<true>(u, Fm);
+          // this layer's update operands (halo layers load them too: no branch around the loads)
+          EpilogueOperands<MODE, P> ops;
+          epilogue_prefetch<MODE, P>(lp, c, a, ops);
+          {
+            const double tc = gamma * lam_sub;
+#pragma unroll
+            for (int bb = 0; bb < N1; ++bb)
+              {
+                const double tbc = fma(beta, Lm[bb], tc);
+#pragma unroll
+                for (int aa = 0; aa < N1; ++aa)
+                  u[bb * 5 + aa] *= fma(alpha, Lm[aa], tbc);
+              }
+          }
+          sweep_slow_eo<false>(u, Fm);
+          // ---- back to layout B; z and x backward sweeps ------------------------------------
+          STAMP(4);
+          transpose5(u, Tw, c);
+          STAMP(5);
+          sweep_slow_eo<false>(u, Fm);
+          sweep_fast_eo<false>(u, Fm);
           STAMP(6);
           merge_xz(c, u, carry);
           STAMP(7);

@@ -220,6 +220,11 @@ namespace asmamd
     std::vector<double> M_ref, K_ref; // [i][j]
     // degree 4: the 9 coefficients of the even-odd form of M_ref / K_ref (see even_odd_coefficients)
     std::vector<double> M_eo, K_eo;
+    // simultaneous diagonalisation of the reference matrices (filled by Basis1D::diagonalise, which
+    // needs generalized_eigen): K_ref Q = M_ref Q diag(lam), Q^T M_ref Q = I, eigenvectors sorted by
+    // parity; F = M_ref Q (row i, column a), so that  M_ref = F F^T  and  K_ref = F diag(lam) F^T
+    std::vector<double> F_ref, lam_ref;
+    void diagonalise();
 
     explicit Basis1D(const int degree)
       : p(degree)
@@ -393,5 +398,38 @@ namespace asmamd
             Q[i * m + a] = con[i] ? 0. : (double)s;
           }
       }
+  }
+
+  inline void
+  Basis1D::diagonalise()
+  {
+    std::vector<double> lam, Q;
+    generalized_eigen(n1, M_ref, K_ref, lam, Q);
+    if (!sort_eigenvectors_by_parity(n1, Q, lam))
+      throw std::runtime_error("reference eigenvectors are not even / odd vectors");
+    F_ref.assign(n1 * n1, 0.);
+    for (int i = 0; i < n1; ++i)
+      for (int a = 0; a < n1; ++a)
+        {
+          long double sum = 0;
+          for (int j = 0; j < n1; ++j)
+            sum += (long double)M_ref[i * n1 + j] * Q[j * n1 + a];
+          F_ref[i * n1 + a] = (double)sum;
+        }
+    // make the parity of the columns of F hold bitwise
+    const int ne = (n1 + 1) / 2;
+    for (int a = 0; a < n1; ++a)
+      {
+        const double sign = a < ne ? 1. : -1.;
+        for (int i = 0; i < n1 / 2; ++i)
+          {
+            const double x           = 0.5 * (F_ref[i * n1 + a] + sign * F_ref[(n1 - 1 - i) * n1 + a]);
+            F_ref[i * n1 + a]           = x;
+            F_ref[(n1 - 1 - i) * n1 + a] = sign * x;
+          }
+        if (sign < 0.)
+          F_ref[(n1 / 2) * n1 + a] = 0.;
+      }
+    lam_ref = lam;
   }
 } // namespace asmamd
