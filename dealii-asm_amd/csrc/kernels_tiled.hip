@@ -1172,6 +1172,7 @@ namespace asmamd
           hy = op.h[1][c.cy + 1];
         }
       const double lam_sub = op.lam_ref[c.sub]; // eigenvalue of the lane's own index in the middle layout
+      const double a_xy = hy / hx, b_xy = hx / hy, g_xy = hx * hy; // layer-invariant parts of the three cell factors
 
       double u[NE]; // the lane's rows (layout B)
       double carry[N1] = {0., 0., 0., 0., 0.};
@@ -1186,7 +1187,7 @@ namespace asmamd
           staged_read<true, true>(g, c, Gw, cz, u);
           gather_release();
           const double hz    = uniform_load(op.h[2], cz + 1);
-          const double alpha = hy * hz / hx, beta = hx * hz / hy, gamma = hx * hy / hz;
+          const double alpha = a_xy * hz, beta = b_xy * hz, gamma = g_xy / hz;
           // lanes without a cell run along unpredicated; nothing of theirs is merged or stored
           // ---- layout B: lane = (cell, y row j), u[k*5 + i]; x and z forward sweeps -------
           STAMP(1);
