@@ -372,22 +372,36 @@ namespace asmamd
     // the data is in flight, every row is read from memory in full lines and exactly once
     // per wave.  A lane then picks its 25 values from the wave-private image.
     // ---------------------------------------------------------------------------
-    struct GatherPlan
-    {
-      int      off[GN]; // in-plane storage offset of the lane's chunk of instruction n
-      unsigned khi;     // bit n: the chunk lies in the higher of the two planes instruction n touches
-    };
+    // rows touched by wave instruction n: planes kmin(n) .. kmax(n)
     __host__ __device__ constexpr int
     gather_kmin(const int n)
     {
       return (64 * n / GCH) / N1;
     }
+    __host__ __device__ constexpr int
+    gather_kmax(const int n)
+    {
+      return ((64 * n + 63) / GCH < NE ? (64 * n + 63) / GCH : NE - 1) / N1;
+    }
+    // Planes 0..3 of a cell layer are consecutive in storage; plane 4 may lie on the other side of a
+    // periodic seam.  Exactly one instruction (GSEAM) covers rows of plane 3 and plane 4.
+    constexpr int GSEAM = 7;
+    static_assert(GN == 10 && gather_kmin(GSEAM) == P - 1 && gather_kmax(GSEAM) == P, "row -> instruction map changed");
+    static_assert(gather_kmax(GSEAM - 1) == P - 1 && gather_kmin(GSEAM + 1) == P, "row -> instruction map changed");
+
+    struct GatherPlan
+    {
+      // byte offset of the lane's chunk of instruction n relative to plane kmin(n) of the layer
+      // (n != GSEAM: including the step to the next plane where the chunk lies in it)
+      unsigned off8[GN];
+      bool     seam_hi; // instruction GSEAM: the lane's chunk lies in plane 4
+    };
 
     __device__ __forceinline__ void
     gather_plan_setup(const DevGrid &g, const int X0, const int Y0, GatherPlan &gp)
     {
       const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-      gp.khi         = 0u;
+      gp.seam_hi     = false;
 #pragma unroll
       for (int n = 0; n < GN; ++n)
         {
@@ -401,82 +415,88 @@ namespace asmamd
           const int k = r / N1, j = r - k * N1;
           const int I = P * X0 + 2 * cc, J = P * (Y0 + w) + j;
           // chunks outside the stored range belong to cells that are not computed: any valid address
-          const int xs = g.exists(0, I) ? g.store_index(0, I) : 0;
-          const int ys = g.exists(1, J) ? g.store_index(1, J) : 0;
-          gp.off[n]    = ys * (int)g.stride[1] + xs;
-          if (k > gather_kmin(n))
-            gp.khi |= 1u << n;
+          const int       xs = g.exists(0, I) ? g.store_index(0, I) : 0;
+          const int       ys = g.exists(1, J) ? g.store_index(1, J) : 0;
+          const long long o  = (long long)ys * g.stride[1] + xs + ((n != GSEAM && k > gather_kmin(n)) ? g.stride[2] : 0);
+          gp.off8[n]         = (unsigned)(o * 8);
+          if (n == GSEAM && k > gather_kmin(n))
+            gp.seam_hi = true;
         }
     }
 
-    // request the rows of cell layer cz: GatherRequest::issue(n0, n1) emits the loads n0 .. n1-1, so
-    // that a caller can spread them over its arithmetic instead of blocking on a full queue
+    // request the rows of cell layer cz (all GN direct-to-LDS loads of the wave)
     struct GatherRequest
     {
       const GatherPlan &gp;
-      const double *    src;
+      const double *    base[N1]; // src + storage offset of plane k (wave-uniform)
       unsigned          lds_base; // LDS byte address of the wave's image (wave-uniform)
-      long long         Z[N1];
       bool              on;
 
       __device__ __forceinline__ GatherRequest(const DevGrid &g, const GatherPlan &plan, const double *s, const int cz,
                                                double *Gw, const bool enabled)
         : gp(plan)
-        , src(s)
         , on(enabled)
       {
         lds_base =
           __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)Gw);
 #pragma unroll
         for (int k = 0; k < N1; ++k)
-          Z[k] = 0;
+          base[k] = s;
         if (enabled)
           {
             const LayerPlanes lp = layer_planes(g, cz);
 #pragma unroll
             for (int k = 0; k < N1; ++k)
-              Z[k] = lp.z[k];
+              base[k] = s + lp.z[k];
           }
       }
 
-      // tie: a value the caller has just computed; it is passed through the asm statement so that
-      // the request keeps its place in the caller's instruction stream (pure arithmetic would
-      // otherwise sink below all requests)
-      template <int N0, int N1_>
       __device__ __forceinline__ void
-      issue(double &tie) const
+      issue() const
       {
 #if defined(ASM_ABLATE) && (ASM_ABLATE & 1)
         return;
 #endif
         if (!on)
           return;
-#pragma unroll
-        for (int n = N0; n < N1_ && n < GN; ++n)
-          {
-            constexpr int   last = N1 - 1;
-            const int       k0 = gather_kmin(n), k1 = k0 < last ? k0 + 1 : last;
-            const long long zo = ((gp.khi >> n) & 1u) ? Z[k1] : Z[k0];
-            const double *  q  = src + zo + gp.off[n];
-            // Issued as an asm statement: hipcc would otherwise drain every pending vector memory
-            // operation (vmcnt(0)) at the next LDS access that might alias the destination, i.e. at
-            // the transposes right behind this request.  The asm form is invisible to the compiler's
-            // wait-count bookkeeping; gather_wait() is the explicit wait that covers it.
-            // M0 holds the wave-uniform LDS destination and is restored afterwards.
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep), "+v"(tie)
-                         : "v"(q), "s"(lds_base + n * 1024u)
-                         : "memory");
-          }
+        // the seam instruction: both planes relative to the lower of the two bases (offsets are unsigned)
+        const double * b_seam = base[P] < base[P - 1] ? base[P] : base[P - 1];
+        const unsigned d_lo = (unsigned)((base[P - 1] - b_seam) * 8), d_hi = (unsigned)((base[P] - b_seam) * 8);
+        const unsigned o_seam = gp.off8[GSEAM] + (gp.seam_hi ? d_hi : d_lo);
+        // One asm statement: hipcc would otherwise drain every pending vector memory operation
+        // (vmcnt(0)) at the next LDS access that might alias the destination, i.e. at the transposes
+        // right behind this request; the asm form is invisible to the compiler's wait-count
+        // bookkeeping and gather_wait() is the explicit wait that covers it.  Scalar base + 32-bit
+        // lane offset addressing; M0 = wave-uniform LDS destination of each 1 KB piece, restored at the end.
+        unsigned keep;
+        asm volatile("s_mov_b32 %[keep], m0\n\t"
+                     "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b0]\n\t"
+                     "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b0]\n\t"
+                     "s_add_u32 m0, %[lds], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b1]\n\t"
+                     "s_add_u32 m0, %[lds], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b1]\n\t"
+                     "s_add_u32 m0, %[lds], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v4], %[b2]\n\t"
+                     "s_add_u32 m0, %[lds], 0x1400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v5], %[b2]\n\t"
+                     "s_add_u32 m0, %[lds], 0x1800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v6], %[b3]\n\t"
+                     "s_add_u32 m0, %[lds], 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v7], %[bs]\n\t"
+                     "s_add_u32 m0, %[lds], 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v8], %[b4]\n\t"
+                     "s_add_u32 m0, %[lds], 0x2400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v9], %[b4]\n\t"
+                     "s_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep)
+                     : [lds] "s"(lds_base), [b0] "s"(base[0]), [b1] "s"(base[1]), [b2] "s"(base[2]), [b3] "s"(base[3]),
+                       [b4] "s"(base[4]), [bs] "s"(b_seam), [v0] "v"(gp.off8[0]), [v1] "v"(gp.off8[1]), [v2] "v"(gp.off8[2]),
+                       [v3] "v"(gp.off8[3]), [v4] "v"(gp.off8[4]), [v5] "v"(gp.off8[5]), [v6] "v"(gp.off8[6]), [v7] "v"(o_seam),
+                       [v8] "v"(gp.off8[8]), [v9] "v"(gp.off8[9])
+                     : "memory", "scc");
       }
     };
+    static_assert(gather_kmin(0) == 0 && gather_kmin(1) == 0 && gather_kmin(2) == 1 && gather_kmin(3) == 1 && gather_kmin(4) == 2 &&
+                    gather_kmin(5) == 2 && gather_kmin(6) == 3 && gather_kmin(8) == 4 && gather_kmin(9) == 4,
+                  "the base operands of GatherRequest::issue follow gather_kmin");
     __device__ __forceinline__ void
     gather_issue(const DevGrid &g, const GatherPlan &gp, const double *__restrict__ src, const int cz, double *Gw)
     {
       const GatherRequest rq(g, gp, src, cz, Gw, true);
-      double              tie = 0.;
-      rq.issue<0, GN>(tie);
+      rq.issue();
     }
 
     // the staged image is complete and may be read / has been read and may be overwritten
@@ -1195,8 +1215,7 @@ namespace asmamd
           sweep_slow_eo<true>(u, Fm);
           // the staged image has been consumed: request the next layer's rows
           const GatherRequest rq(g, gp, a.src, cz + 1, Gw, cz + 1 < Ze);
-          double              no_tie = 0.;
-          rq.issue<0, GN>(no_tie);
+          rq.issue();
           // ---- layout A: lane = (cell, z index c), u[b*5 + a]; y sweeps + scaling ---------
           STAMP(2);
           transpose5(u, Tw, c);
