@@ -7,9 +7,13 @@
 //     all the cells that contribute to it);
 //   * wave w handles cell row w of the tile: 12 cells x 5 lanes, a lane holds one
 //     5 x 5 slice of the cell's 5 x 5 x 5 patch tile in registers;
+//   * the source rows of a layer (5 planes x 5 DoF rows x 49 DoFs per wave) are copied
+//     global -> LDS by direct-to-LDS loads one layer ahead, in full lines, and picked
+//     up from the wave-private image;
 //   * two 1-D sweep directions run on registers, the third direction is reached
 //     by a 5-lane transpose through a small wave-private LDS buffer (no workgroup
-//     barrier involved);
+//     barrier involved); matrices whose columns are even / odd vectors are applied in
+//     even-odd form (13 products per line) with wave-uniform scalar operands;
 //   * contributions to shared DoFs are merged where they are produced: in x by a
 //     5-lane shift inside the wave, in z through registers the lane keeps from one
 //     layer to the next, in y through a 20-double LDS slot per cell (one barrier per
@@ -20,6 +24,8 @@
 // 1023-1062), the cell loop of LaplaceOperatorMatrixFree::vmult (include/operator.h:
 // 1367-1430) and the pre/post lambdas PreconditionChebyshev hands to both: dst needs
 // no zeroing, no atomics and no compress(add); results are bitwise reproducible.
+// Diagnostic builds: -DASM_ABLATE=<bit mask> removes parts of the kernels (results wrong on
+// purpose, tools/ablate.sh), -DASM_STAMP adds s_memtime stamps (tools/stamp_run.py).
 #include "kernels.h"
 #include "numerics.h"
 
@@ -45,10 +51,7 @@ namespace asmamd
     constexpr int N1  = 5;
     constexpr int NE  = 25;       // values per cell plane
     constexpr int WX  = 12;       // cells per wave (x)
-#ifndef ASM_TY
-#  define ASM_TY 8
-#endif
-    constexpr int TY  = ASM_TY;   // cell rows per tile = waves per workgroup
+    constexpr int TY  = 8;        // cell rows per tile = waves per workgroup
     constexpr int OX  = WX - 1;   // owned cells per tile, x
     constexpr int OY  = TY - 1;   // owned cells per tile, y
     constexpr int NT  = TY * 64;  // threads
@@ -68,8 +71,8 @@ namespace asmamd
     constexpr int GN        = (NE * GCH + 63) / 64; // wave instructions per layer (10)
     constexpr int GBUF      = GN * 128;          // doubles per wave
     constexpr int LDS_G     = TY * GBUF;
-    constexpr int LDS_FLAG  = TY;                // 2 x TY ints: y-merge hand-off counters
-    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_G + LDS_TAB + LDS_INV + LDS_FLAG;
+    constexpr int LDS_TOTAL = LDS_T + LDS_Y + LDS_G + LDS_TAB + LDS_INV;
+    static_assert(LDS_TOTAL * sizeof(double) <= 160 * 1024, "one workgroup must fit the 160 KB LDS of a CU");
 
 #ifdef ASM_STAMP
     // diagnostic build: cycles (s_memtime) an interior wave spends between the STAMP marks
@@ -557,11 +560,7 @@ namespace asmamd
 #if defined(ASM_ABLATE) && (ASM_ABLATE & 64)
       return; // diagnostic build (results are wrong)
 #endif
-#if defined(ASM_TRANSPOSE_WAIT)
-#  define TRANSPOSE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
-#  define TRANSPOSE_FENCE() asm volatile("" ::: "memory")
-#endif
+#define TRANSPOSE_FENCE() asm volatile("" ::: "memory")
       // lanes 60..63 hold no cell: they run along unpredicated (their cl = 12 slots exist)
 #pragma unroll
       for (int f = 0; f < N1; ++f)
@@ -629,9 +628,6 @@ namespace asmamd
       for (int k = 0; k < NPL; ++k)
         {
           const long long off = lp.z[k] + c.rowoff;
-#if defined(ASM_OPS_PRED)
-          if (c.own_row)
-#endif
 #pragma unroll
           for (int i = 0; i < P; ++i)
             {
@@ -707,35 +703,13 @@ namespace asmamd
         }
     }
 
-    // Hand-off of the y-merge slots between neighbouring waves.  A wave only depends on the wave
-    // below it (which produces its row 0 share) and, for slot reuse, on the wave above it, so the
-    // waves of a workgroup are not forced through a common barrier every layer and may drift apart
-    // by up to two layers: their memory phases and compute phases then overlap.
-    // prod[w] = last layer whose slot wave w has written, cons[w] = last layer wave w has read.
-    struct YSync
-    {
-      volatile int *prod, *cons;
-      int           seq; // running number of the merge (same in every wave)
-    };
-    [[maybe_unused]] __device__ __forceinline__ void
-    spin_until(volatile int *flag, const int n)
-    {
-      while (__builtin_amdgcn_readfirstlane(*flag) < n)
-        __builtin_amdgcn_s_sleep(1);
-    }
-
     template <int MODE, int NPL>
     __device__ __forceinline__ void
     merge_y_and_store(const DevGrid &g, const LayerPlanes &lp, const CellLane &c, const TiledArgs &a, double *__restrict__ Sy,
-                      double (&o)[NE], const int K0, const EpilogueOperands<MODE, NPL> &ops, YSync &ys STAMP_PARAM)
+                      double (&o)[NE], const int K0, const EpilogueOperands<MODE, NPL> &ops STAMP_PARAM)
     {
 #if !(defined(ASM_ABLATE) && (ASM_ABLATE & 8))
       // ---- y: row 4 -> row 0 of the cell above
-#if defined(ASM_FLAGS)
-      const int n = ys.seq++;
-      if (c.w + 1 < TY)
-        spin_until(ys.cons + c.w + 1, n - 2); // the slot's previous content (two layers ago) has been read
-#endif
       if (c.cell_xy && c.sub == N1 - 1)
         {
           double *slot = Sy + (c.w * WX + c.cl) * YS;
@@ -746,16 +720,7 @@ namespace asmamd
               slot[k * 5 + i] = o[k * 5 + i];
         }
       STAMP(10);
-#if defined(ASM_FLAGS)
-      // LDS executes a wave's instructions in order: whoever sees the counter sees the slot
-      asm volatile("" ::: "memory");
-      ys.prod[c.w] = n;
-      if (c.w >= 1)
-        spin_until(ys.prod + c.w - 1, n);
-      asm volatile("" ::: "memory");
-#else
       __syncthreads();
-#endif
       STAMP(11);
       if (c.below_ok && c.sub == 0)
         {
@@ -766,10 +731,6 @@ namespace asmamd
             for (int i = 0; i < N1; ++i)
               o[k * 5 + i] += slot[k * 5 + i];
         }
-#endif
-#if defined(ASM_FLAGS)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ys.cons[c.w] = n;
 #endif
       STAMP(12);
       // the next layer's staged rows (requested long ago) and the update operands have arrived;
@@ -869,22 +830,12 @@ namespace asmamd
       GatherPlan gp;
       gather_plan_setup(g, X0, Y0, gp);
 
-      YSync ys;
       double *S_inv = S_tab + LDS_TAB;
-      ys.prod       = (volatile int *)(S_inv + LDS_INV);
-      ys.cons = ys.prod + TY;
-      ys.seq  = 0;
-      if (threadIdx.x < 2 * TY)
-        ys.prod[threadIdx.x] = -1;
       // eigen tables of tensor-product meshes live in LDS (the launcher checks n_inst <= 16)
       if (TENSOR)
         for (int e = threadIdx.x; e < f.n_inst * EIG; e += NT)
           S_tab[e] = f.eig[e];
       __syncthreads();
-#if defined(ASM_SKEW)
-      for (int i = 0; i < (int)(threadIdx.x >> 6) * ASM_SKEW; ++i)
-        __builtin_amdgcn_s_sleep(16);
-#endif
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
@@ -1118,7 +1069,7 @@ namespace asmamd
           STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops, ys STAMP_ARG);
+              merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops STAMP_ARG);
               par ^= 1;
             }
           else
@@ -1136,7 +1087,7 @@ namespace asmamd
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             v[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops, ys STAMP_ARG);
+          merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops STAMP_ARG);
         }
     }
 
@@ -1170,14 +1121,6 @@ namespace asmamd
       double *Gw = S_G + c.w * GBUF;
       GatherPlan gp;
       gather_plan_setup(g, X0, Y0, gp);
-
-      YSync ys;
-      ys.prod = (volatile int *)(S_G + LDS_G + LDS_TAB + LDS_INV);
-      ys.cons = ys.prod + TY;
-      ys.seq  = 0;
-      if (threadIdx.x < 2 * TY)
-        ys.prod[threadIdx.x] = -1;
-      __syncthreads();
 
       // F (row i, column a) and the eigenvalues: wave-uniform scalar operands
       const UniformMatrix Fm(op.F_ref);
@@ -1247,7 +1190,7 @@ namespace asmamd
           STAMP(7);
           if (cz >= Zb)
             {
-              merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops, ys STAMP_ARG);
+              merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (LDS_Y / 2), u, P * cz, ops STAMP_ARG);
               par ^= 1;
             }
           else
@@ -1263,7 +1206,7 @@ namespace asmamd
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             u[i] = carry[i];
-          merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops, ys STAMP_ARG);
+          merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops STAMP_ARG);
         }
     }
 
