@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--degree", type=int, default=1, help="Chebyshev degree (amd-opt_fdm1_cart.json: 1)")
     ap.add_argument("--what", default="cheb_step", choices=["cheb_step", "cheb_vmult"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled"])
+    ap.add_argument("--n-overlap", type=int, default=1, help="element-centred patches: cell + (n-1) DoF layers")
+    ap.add_argument("--patch", default="cell", choices=["cell", "vertex"], help="element-centred or vertex-star patches")
+    ap.add_argument("--weighting", default="post", choices=["none", "pre", "post", "symm", "ras"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (CPU share of one GPU)")
     args = ap.parse_args()
@@ -151,8 +154,9 @@ def main():
         kershaw_eps=(0.3, 0.3),
         extent=extent,
         precond="FDM",
-        n_overlap=1,
-        weighting="post",
+        n_overlap=args.n_overlap,
+        weighting=args.weighting,
+        element_centric=args.patch == "cell",
         cheb_degree=args.degree,
         kernel=args.kernel,
         device=local_rank,
@@ -257,7 +261,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload} p=4 {n_cells[0]}x{n_cells[1]}x{n_cells[2]} cells, "
-                f"Chebyshev degree {args.degree} {args.what.split('_')[1]}(), FDM n_overlap=1 post weights",
+                f"Chebyshev degree {args.degree} {args.what.split('_')[1]}(), FDM "
+                + (f"n_overlap={args.n_overlap}" if args.patch == "cell" else "vertex-star")
+                + f" {args.weighting} weights",
                 "n_dofs": n_dofs,
                 "cells_per_gpu": list(cells),
                 "proc_grid": grid,

@@ -630,35 +630,24 @@ namespace asmamd
           const long long off = lp.z[k] + c.rowoff;
 #pragma unroll
           for (int i = 0; i < P; ++i)
-            {
-              ops.a[k * P + i] = pa[off + i];
-              if (EpilogueOperands<MODE, NPL>::need_b)
-                ops.b[k * P + i] = a.x_old[off + i];
-            }
+            ops.a[k * P + i] = pa[off + i];
         }
     }
-
-    // the same for one plane (callers spread the loads over their arithmetic)
-    template <int MODE, int NPL, int K>
+    // second operand of the three-term update (x_old): requested later than the first one, after the
+    // sweeps (fewer registers are live there); the y-merge barrier covers part of its latency
+    template <int MODE, int NPL>
     __device__ __forceinline__ void
-    epilogue_prefetch_plane(const LayerPlanes &lp, const CellLane &c, const TiledArgs &a, EpilogueOperands<MODE, NPL> &ops,
-                            const bool enabled)
+    epilogue_prefetch_second(const LayerPlanes &lp, const CellLane &c, const TiledArgs &a, EpilogueOperands<MODE, NPL> &ops)
     {
-      if (!EpilogueOperands<MODE, NPL>::need_a || !enabled)
+      if (!EpilogueOperands<MODE, NPL>::need_b)
         return;
-#if defined(ASM_ABLATE) && (ASM_ABLATE & 2)
-      for (int i = 0; i < P; ++i)
-        ops.a[K * P + i] = 1.0 + i;
-      return;
-#endif
-      const double *  pa  = (MODE == OP_RESIDUAL) ? a.b : a.x;
-      const long long off = lp.z[K] + c.rowoff;
 #pragma unroll
-      for (int i = 0; i < P; ++i)
+      for (int k = 0; k < NPL; ++k)
         {
-          ops.a[K * P + i] = pa[off + i];
-          if (EpilogueOperands<MODE, NPL>::need_b)
-            ops.b[K * P + i] = a.x_old[off + i];
+          const long long off = lp.z[k] + c.rowoff;
+#pragma unroll
+          for (int i = 0; i < P; ++i)
+            ops.b[k * P + i] = a.x_old[off + i];
         }
     }
 
@@ -1069,6 +1058,7 @@ namespace asmamd
           STAMP(7);
           if (cz >= Zb)
             {
+              epilogue_prefetch_second<MODE, P>(lp, c, a, ops);
               merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * cz, ops STAMP_ARG);
               par ^= 1;
             }
@@ -1084,6 +1074,7 @@ namespace asmamd
           EpilogueOperands<MODE, 1> ops;
           const LayerPlanes         lp = layer_planes(g, g.nc[2]);
           epilogue_prefetch<MODE, 1>(lp, c, a, ops);
+          epilogue_prefetch_second<MODE, 1>(lp, c, a, ops);
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             v[i] = carry[i];
@@ -1203,6 +1194,7 @@ namespace asmamd
           EpilogueOperands<MODE, 1> ops;
           const LayerPlanes         lp = layer_planes(g, g.nc[2]);
           epilogue_prefetch<MODE, 1>(lp, c, a, ops);
+          epilogue_prefetch_second<MODE, 1>(lp, c, a, ops);
 #pragma unroll
           for (int i = 0; i < N1; ++i)
             u[i] = carry[i];
