@@ -70,6 +70,21 @@ class AsmLayout(C.Structure):
     ]
 
 
+class AsmDirectMessage(C.Structure):
+    _fields_ = [
+        ("peer", C.c_int32),
+        ("offset", C.c_int32 * 3),
+        ("send_lo", C.c_int32 * 3),
+        ("send_size", C.c_int32 * 3),
+        ("recv_lo", C.c_int32 * 3),
+        ("recv_size", C.c_int32 * 3),
+        ("send_offset", C.c_int64),
+        ("recv_offset", C.c_int64),
+        ("send_count", C.c_int64),
+        ("recv_count", C.c_int64),
+    ]
+
+
 class AsmExchangeStep(C.Structure):
     _fields_ = [
         ("direction", C.c_int32),
@@ -89,6 +104,7 @@ EXPORTED_SYMBOLS = [
     "asm_last_error",
     "asm_describe_layout",
     "asm_exchange_plan",
+    "asm_exchange_plan_direct",
     "asm_comm_unique_id",
     "asm_comm_init",
     "asm_vector_layout",
@@ -140,6 +156,7 @@ def load_library():
     lib.asm_destroy.restype = None
     lib.asm_describe_layout.argtypes = [C.POINTER(AsmParams), C.POINTER(AsmLayout)]
     lib.asm_exchange_plan.argtypes = [C.POINTER(AsmParams), C.c_int, C.POINTER(AsmExchangeStep), C.POINTER(C.c_int32)]
+    lib.asm_exchange_plan_direct.argtypes = [C.POINTER(AsmParams), C.POINTER(AsmDirectMessage), C.POINTER(C.c_int32)]
     lib.asm_vector_layout.argtypes = [C.c_void_p, C.POINTER(AsmLayout)]
     lib.asm_vector_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.asm_vector_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -237,6 +254,17 @@ def describe_layout(params: AsmParams) -> AsmLayout:
     if err:
         raise ValueError(lib.asm_last_error(None).decode())
     return out
+
+
+def exchange_plan_direct(params: AsmParams):
+    """list of asm_direct_message: the single-round form of update_ghost_values"""
+    lib = load_library()
+    msgs = (AsmDirectMessage * 26)()
+    n = C.c_int32()
+    err = lib.asm_exchange_plan_direct(C.byref(params), msgs, C.byref(n))
+    if err:
+        raise ValueError(lib.asm_last_error(None).decode())
+    return [msgs[i] for i in range(n.value)]
 
 
 def exchange_plan(params: AsmParams, add: bool):

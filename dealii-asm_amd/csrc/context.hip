@@ -50,6 +50,11 @@ struct asm_ctx
   double *                 hbuf[4]    = {nullptr, nullptr, nullptr, nullptr}; // send lo/hi, recv lo/hi
   long long                hbuf_size  = 0;
   bool                     external_exchange = false; // testing aid: ghosts are exchanged by asm_debug_exchange_all
+  // single-round ghost update (update_ghost_values of the tiled kernels): setup.h: build_direct_plan
+  asm_direct_message       dmsg[26];
+  int                      n_dmsg = 0;
+  BoxList                  dsend, drecv;
+  double *                 dbuf[2] = {nullptr, nullptr}; // send, receive
   // optional per-kernel timing with HIP events on the context's stream
   bool                                           profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[2];
@@ -165,7 +170,24 @@ namespace
         ctx->error = "world_size > 1 but asm_comm_init() has not been called";
         return ASM_ERR_INVALID_VALUE;
       }
-    const DevGrid &   g = ctx->g;
+    const DevGrid &g = ctx->g;
+    if (!add && ctx->n_dmsg > 0)
+      {
+        // one round: pack all boxes, one grouped send/recv with every neighbour, unpack all boxes
+        vec_boxes(g, 0, v, ctx->dbuf[0], ctx->dsend, ctx->stream);
+        NCCL_TRY(ncclGroupStart());
+        for (int i = 0; i < ctx->n_dmsg; ++i)
+          if (ctx->dmsg[i].send_count > 0)
+            NCCL_TRY(ncclSend(ctx->dbuf[0] + ctx->dmsg[i].send_offset, ctx->dmsg[i].send_count, ncclDouble, ctx->dmsg[i].peer,
+                              ctx->comm, ctx->stream));
+        for (int i = ctx->n_dmsg - 1; i >= 0; --i)
+          if (ctx->dmsg[i].recv_count > 0)
+            NCCL_TRY(ncclRecv(ctx->dbuf[1] + ctx->dmsg[i].recv_offset, ctx->dmsg[i].recv_count, ncclDouble, ctx->dmsg[i].peer,
+                              ctx->comm, ctx->stream));
+        NCCL_TRY(ncclGroupEnd());
+        vec_boxes(g, 1, v, ctx->dbuf[1], ctx->drecv, ctx->stream);
+        return ASM_OK;
+      }
     asm_exchange_step steps[3];
     const int         n_steps = build_exchange_plan(ctx->s, add, steps);
     for (int i = 0; i < n_steps; ++i)
@@ -495,6 +517,19 @@ asm_exchange_plan(const asm_params *p, int add, asm_exchange_step steps[3], int3
 }
 
 int
+asm_exchange_plan_direct(const asm_params *p, asm_direct_message msgs[26], int32_t *n_msgs)
+{
+  HostSetup s;
+  if (!setup_layout(*p, s))
+    {
+      g_create_error = s.error;
+      return ASM_ERR_INVALID_VALUE;
+    }
+  *n_msgs = build_direct_plan(s, msgs);
+  return ASM_OK;
+}
+
+int
 asm_create(const asm_params *p, asm_ctx **out)
 {
   *out = nullptr;
@@ -628,6 +663,34 @@ asm_create(const asm_params *p, asm_ctx **out)
               return fail(ASM_ERR_DEVICE);
             }
           ctx->allocs.push_back(ctx->hbuf[i]);
+        }
+      // single-round plan of the ghost update
+      ctx->n_dmsg  = build_direct_plan(s, ctx->dmsg);
+      ctx->dsend.n = ctx->drecv.n = ctx->n_dmsg;
+      long long total[2]          = {0, 0};
+      for (int i = 0; i < ctx->n_dmsg; ++i)
+        {
+          const asm_direct_message &m = ctx->dmsg[i];
+          for (int d = 0; d < 3; ++d)
+            {
+              ctx->dsend.lo[i][d]   = m.send_lo[d];
+              ctx->dsend.size[i][d] = m.send_size[d];
+              ctx->drecv.lo[i][d]   = m.recv_lo[d];
+              ctx->drecv.size[i][d] = m.recv_size[d];
+            }
+          ctx->dsend.offset[i] = m.send_offset;
+          ctx->drecv.offset[i] = m.recv_offset;
+          total[0] += m.send_count;
+          total[1] += m.recv_count;
+        }
+      for (int i = 0; i < 2; ++i)
+        {
+          if (hipMalloc((void **)&ctx->dbuf[i], std::max(1ll, total[i]) * sizeof(double)) != hipSuccess)
+            {
+              ctx->error = "halo buffer allocation failed";
+              return fail(ASM_ERR_DEVICE);
+            }
+          ctx->allocs.push_back(ctx->dbuf[i]);
         }
     }
   if (s.prm.precond_type == ASM_PRECOND_DIAGONAL)
@@ -1020,6 +1083,37 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
         ctxs[r]->error = "asm_debug_exchange_all: ctxs[r] must be rank r of n";
         return ASM_ERR_INVALID_VALUE;
       }
+  if (!add && ctxs[0]->n_dmsg > 0)
+    {
+      // single-round plan: what rank r receives from offset o is what its peer sends towards -o
+      for (int r = 0; r < n; ++r)
+        vec_boxes(ctxs[r]->g, 0, vecs[r], ctxs[r]->dbuf[0], ctxs[r]->dsend, ctxs[r]->stream);
+      HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
+      for (int r = 0; r < n; ++r)
+        for (int i = 0; i < ctxs[r]->n_dmsg; ++i)
+          {
+            const asm_direct_message &m = ctxs[r]->dmsg[i];
+            if (m.recv_count == 0)
+              continue;
+            const asm_ctx *           pc = ctxs[m.peer];
+            const asm_direct_message *pm = nullptr;
+            for (int j = 0; j < pc->n_dmsg; ++j)
+              if (pc->dmsg[j].peer == r && pc->dmsg[j].offset[0] == -m.offset[0] && pc->dmsg[j].offset[1] == -m.offset[1] &&
+                  pc->dmsg[j].offset[2] == -m.offset[2])
+                pm = &pc->dmsg[j];
+            if (pm == nullptr || pm->send_count != m.recv_count)
+              {
+                ctxs[r]->error = "asm_debug_exchange_all: send and receive boxes do not match";
+                return ASM_ERR_INVALID_VALUE;
+              }
+            HIP_TRY_CTX(ctxs[r], hipMemcpy(ctxs[r]->dbuf[1] + m.recv_offset, pc->dbuf[0] + pm->send_offset,
+                                           m.recv_count * sizeof(double), hipMemcpyDeviceToDevice));
+          }
+      for (int r = 0; r < n; ++r)
+        vec_boxes(ctxs[r]->g, 1, vecs[r], ctxs[r]->dbuf[1], ctxs[r]->drecv, ctxs[r]->stream);
+      HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
+      return ASM_OK;
+    }
   std::vector<std::array<asm_exchange_step, 3>> steps(n);
   int                                           n_steps = 0;
   for (int r = 0; r < n; ++r)

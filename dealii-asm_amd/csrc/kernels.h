@@ -58,4 +58,12 @@ namespace asmamd
   // box copy between a packed buffer and a vector (halo exchange, import/export)
   // mode 0: buf <- vec ; 1: vec <- buf ; 2: vec += buf ; 3: vec <- 0
   void vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st);
+  // the same for up to 26 boxes in one launch: box b is copied to / from buf + offset[b]
+  struct BoxList
+  {
+    int       n;
+    int       lo[26][3], size[26][3];
+    long long offset[26];
+  };
+  void vec_boxes(const DevGrid &g, int mode, double *vec, double *buf, const BoxList &boxes, hipStream_t st);
 } // namespace asmamd

@@ -223,6 +223,23 @@ namespace asmamd
             vec[o] = 0.;
         }
     }
+    __global__ void __launch_bounds__(VB)
+    boxes_kernel(const DevGrid g, const int mode, double *__restrict__ vec, double *__restrict__ buf, const BoxList bl)
+    {
+      const int       b  = blockIdx.y;
+      const int       s0 = bl.size[b][0], s1 = bl.size[b][1], s2 = bl.size[b][2];
+      const long long n  = (long long)s0 * s1 * s2;
+      double *        bb = buf + bl.offset[b];
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          const int       i = (int)(e % s0), j = (int)((e / s0) % s1), k = (int)(e / ((long long)s0 * s1));
+          const long long o = g.offset(bl.lo[b][0] + i, bl.lo[b][1] + j, bl.lo[b][2] + k);
+          if (mode == 0)
+            bb[e] = vec[o];
+          else
+            vec[o] = bb[e];
+        }
+    }
   } // namespace
 
   void
@@ -293,5 +310,15 @@ namespace asmamd
       return;
     hipLaunchKernelGGL(box_kernel, dim3(grid_for(n, 4)), dim3(VB), 0, st, g, mode, vec, buf, lo[0], lo[1], lo[2], size[0],
                        size[1], size[2]);
+  }
+  void
+  vec_boxes(const DevGrid &g, int mode, double *vec, double *buf, const BoxList &boxes, hipStream_t st)
+  {
+    if (boxes.n <= 0)
+      return;
+    long long largest = 1;
+    for (int b = 0; b < boxes.n; ++b)
+      largest = std::max(largest, (long long)boxes.size[b][0] * boxes.size[b][1] * boxes.size[b][2]);
+    hipLaunchKernelGGL(boxes_kernel, dim3(grid_for(largest, 4), boxes.n), dim3(VB), 0, st, g, mode, vec, buf, boxes);
   }
 } // namespace asmamd

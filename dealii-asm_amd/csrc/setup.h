@@ -325,6 +325,86 @@ namespace asmamd
       }
   }
 
+  // Single-round ghost update: one box to / from each of the up to 26 neighbouring blocks.
+  // Per direction d a neighbour offset o_d selects a zone of planes:
+  //   o_d =  0: the owned planes [0, own_hi] on both sides;
+  //   o_d = +1: I send my top planes [np - n_lo, np) (its low ghosts), I receive its planes
+  //             [0, n_hi) as my high ghosts [np, np + n_hi);
+  //   o_d = -1: I send my planes [0, n_hi) (its high ghosts), I receive my low ghosts [-n_lo, 0).
+  // (a shared plane belongs to the block on its high side).  The box of a message is the product
+  // of its three zones; what I send towards o is what that neighbour receives from -o.
+  // Order: sends in the order of the array (lexicographic in the offset), receives in reverse
+  // order, so that between two ranks that are each other's neighbours more than once (two blocks in
+  // a periodic direction) the k-th send meets the k-th receive.
+  inline int
+  build_direct_plan(const HostSetup &s, asm_direct_message msgs[26])
+  {
+    const DevGrid &g    = s.g;
+    const int      n_lo = s.halo_lo, n_hi = s.halo_hi;
+    int            n    = 0;
+    long long      so = 0, ro = 0;
+    for (int oz = -1; oz <= 1; ++oz)
+      for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox)
+          {
+            const int o[3] = {ox, oy, oz};
+            if (ox == 0 && oy == 0 && oz == 0)
+              continue;
+            bool exists = true;
+            int  pcn[3];
+            for (int d = 0; d < 3; ++d)
+              {
+                pcn[d] = s.pc[d];
+                if (o[d] == 0)
+                  continue;
+                if (s.face[d][o[d] > 0 ? 1 : 0] != FACE_INTERFACE)
+                  exists = false;
+                pcn[d] = imod(s.pc[d] + o[d], s.P[d]);
+              }
+            if (!exists)
+              continue;
+            asm_direct_message &m = msgs[n];
+            m.peer                = pcn[0] + s.P[0] * (pcn[1] + s.P[1] * pcn[2]);
+            long long sc = 1, rc = 1;
+            for (int d = 0; d < 3; ++d)
+              {
+                const int np = g.nc[d] * g.p;
+                m.offset[d]  = o[d];
+                if (o[d] == 0)
+                  {
+                    m.send_lo[d] = m.recv_lo[d] = 0;
+                    m.send_size[d] = m.recv_size[d] = g.own_hi[d] + 1;
+                  }
+                else if (o[d] > 0)
+                  {
+                    m.send_lo[d]   = np - n_lo;
+                    m.send_size[d] = n_lo;
+                    m.recv_lo[d]   = np;
+                    m.recv_size[d] = n_hi;
+                  }
+                else
+                  {
+                    m.send_lo[d]   = 0;
+                    m.send_size[d] = n_hi;
+                    m.recv_lo[d]   = -n_lo;
+                    m.recv_size[d] = n_lo;
+                  }
+                sc *= m.send_size[d];
+                rc *= m.recv_size[d];
+              }
+            if (sc == 0 && rc == 0)
+              continue;
+            m.send_offset = so;
+            m.recv_offset = ro;
+            m.send_count  = sc;
+            m.recv_count  = rc;
+            so += sc;
+            ro += rc;
+            ++n;
+          }
+    return n;
+  }
+
   // ---------------------------------------------------------------------
   // ghost exchange plan: dimension-by-dimension slabs (x, then y with the x ghosts,
   // then z), the structured-block equivalent of Partitioner::export_to_ghosted_array

@@ -162,6 +162,19 @@ typedef struct asm_exchange_step
   int32_t recv_lo[2][3], recv_size[2][3];
 } asm_exchange_step;
 
+/* one message of the single-round ghost update (update_ghost_values of the tiled kernels):
+ * the rank exchanges one box with each of its up to 26 face, edge and corner neighbours;
+ * boxes in LOCAL logical DoF coordinates, offsets (in doubles) into one send and one
+ * receive buffer.  Sends are posted in the order of the array, receives in reverse order. */
+typedef struct asm_direct_message
+{
+  int32_t peer;      /* rank of the neighbour */
+  int32_t offset[3]; /* its block coordinate minus mine, each in {-1, 0, 1} */
+  int32_t send_lo[3], send_size[3];
+  int32_t recv_lo[3], recv_size[3];
+  int64_t send_offset, recv_offset, send_count, recv_count;
+} asm_direct_message;
+
 /* ----- life cycle ------------------------------------------------------- */
 
 /* fills *p with the reference's defaults */
@@ -183,6 +196,8 @@ int asm_describe_layout(const asm_params *p, asm_layout *out);
  * afterwards) that rank `p->rank` executes; this is the plan asm_update_ghost_values
  * / asm_compress_add run over RCCL.  Needs no GPU. */
 int asm_exchange_plan(const asm_params *p, int add, asm_exchange_step steps[3], int32_t *n_steps);
+/* the single-round form of update_ghost_values (no GPU needed): up to 26 messages */
+int asm_exchange_plan_direct(const asm_params *p, asm_direct_message msgs[26], int32_t *n_msgs);
 
 /* RCCL bootstrap: rank 0 fills a 128-byte id, the host broadcasts it, every rank
  * joins.  Replaces the MPI communicator held by deal.II's Partitioner. */

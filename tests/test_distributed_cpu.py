@@ -47,6 +47,31 @@ def _run_plan(steps, box, layout, add):
                     view(list(st.send_lo[side]), list(st.send_size[side]))[...] = 0.0
 
 
+def _run_direct_plan(msgs, box, layout):
+    """single-round update (asm_exchange_plan_direct): sends in array order, receives in reverse
+    order, one tag: what RCCL's per-pair FIFO matching does"""
+    lo0 = [layout.store_begin[d] for d in range(3)]
+
+    def view(lo, size):
+        sl = tuple(slice(lo[d] - lo0[d], lo[d] - lo0[d] + size[d]) for d in (2, 1, 0))
+        return box[sl]
+
+    reqs, recv_bufs = [], []
+    for m in msgs:
+        if m.send_count > 0:
+            buf = torch.from_numpy(np.ascontiguousarray(view(list(m.send_lo), list(m.send_size))))
+            reqs.append(dist.isend(buf, m.peer))
+    for m in reversed(msgs):
+        if m.recv_count > 0:
+            buf = torch.empty(tuple(m.recv_size[d] for d in (2, 1, 0)), dtype=torch.float64)
+            recv_bufs.append((m, buf))
+            reqs.append(dist.irecv(buf, m.peer))
+    for r in reqs:
+        r.wait()
+    for m, buf in recv_bufs:
+        view(list(m.recv_lo), list(m.recv_size))[...] = buf.numpy()
+
+
 def _worker(rank, world, port, case, result_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -87,7 +112,11 @@ def _worker(rank, world, port, case, result_q):
     gsl = tuple(slice(gb[d], gb[d] + own[d]) for d in (2, 1, 0))
     box[osl] = glob(x)[gsl]
     _run_plan(pkg.exchange_plan(prm, False), box, L, add=False)
-    ok_update = True
+    box2 = np.full((store[2], store[1], store[0]), np.nan)
+    box2[osl] = glob(x)[gsl]
+    _run_direct_plan(pkg.exchange_plan_direct(prm), box2, L)
+    # both plans fill the same ghost entries with the same values
+    ok_update = bool(np.array_equal(np.isnan(box), np.isnan(box2)) and np.array_equal(np.nan_to_num(box), np.nan_to_num(box2)))
     for k in range(store[2]):
         for j in range(store[1]):
             K, J = k + lo0[2], j + lo0[1]
@@ -148,8 +177,11 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[2]}-{c[3]}")
+@pytest.mark.parametrize(
+    "world,case",
+    [(w, c) for w in (2, 4) for c in CASES] + [(8, CASES[4]), (8, CASES[5])],
+    ids=lambda v: str(v) if isinstance(v, int) else f"{v[2]}-{v[3]}",
+)
 def test_exchange_plan_gloo(case, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
