@@ -170,6 +170,9 @@ def main():
         uid = [pkg.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0])
+        # the timed loop modifies its vectors through the library only: the exchange of a step's result
+        # (overlapped with the sweep that produces it) then serves the next step, as asm_set_keep_ghosts documents
+        ctx.set_keep_ghosts(True)
 
     def barrier():
         ctx.synchronize()

@@ -127,7 +127,10 @@ EXPORTED_SYMBOLS = [
     "asm_kernel_variant_in_use",
     "asm_synchronize",
     "asm_time_calls",
+    "asm_set_keep_ghosts",
     "asm_debug_external_exchange",
+    "asm_debug_two_phase",
+    "asm_debug_loopback_init",
     "asm_debug_exchange_all",
     "asm_profile_enable",
     "asm_profile_get",
@@ -174,7 +177,10 @@ def load_library():
     lib.asm_kernel_variant_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_synchronize.argtypes = [C.c_void_p]
     lib.asm_time_calls.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.asm_set_keep_ghosts.argtypes = [C.c_void_p, C.c_int]
     lib.asm_debug_external_exchange.argtypes = [C.c_void_p, C.c_int]
+    lib.asm_debug_two_phase.argtypes = [C.c_void_p, C.c_int]
+    lib.asm_debug_loopback_init.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.asm_debug_exchange_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int]
     lib.asm_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.asm_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -278,6 +284,16 @@ def exchange_plan(params: AsmParams, add: bool):
     return [steps[i] for i in range(n.value)]
 
 
+def loopback_init(contexts):
+    """Testing aid (asm_debug_loopback_init): contexts[r] = rank r; drive every rank from its own thread."""
+    lib = load_library()
+    n = len(contexts)
+    cs = (C.c_void_p * n)(*[c.handle for c in contexts])
+    err = lib.asm_debug_loopback_init(cs, n)
+    if err:
+        raise RuntimeError(f"asm_debug_loopback_init failed ({err}): {lib.asm_last_error(contexts[0].handle).decode()}")
+
+
 def exchange_all(contexts, vectors, add=False):
     """Testing aid (asm_debug_exchange_all): ghost exchange of vectors[r] of contexts[r], r = rank,
     for all ranks of a partition living in this process."""
@@ -359,6 +375,14 @@ class Context:
     @property
     def n_dofs(self):
         return int(self.layout.n_global_dofs)
+
+    def set_keep_ghosts(self, on=True):
+        """Promise: vectors are only modified through the library between calls (asm_set_keep_ghosts)."""
+        self._check(self.lib.asm_set_keep_ghosts(self.handle, 1 if on else 0))
+
+    def two_phase(self, on=True):
+        """Testing aid: tiled sweeps as boundary + interior launches (asm_debug_two_phase)."""
+        self._check(self.lib.asm_debug_two_phase(self.handle, 1 if on else 0))
 
     def external_exchange(self, on=True):
         """Testing aid: vmult/step leave the ghost exchange to exchange_all()."""

@@ -13,7 +13,10 @@
 #include <rccl/rccl.h>
 
 #include <array>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -29,6 +32,33 @@ namespace asmamd
 using namespace asmamd;
 
 static thread_local std::string g_create_error;
+
+// Testing aid: the ranks of a partition as contexts of ONE process, driven by one host thread per
+// rank (asm_debug_loopback_init).  Send/recv become device-to-device copies between the ranks'
+// buffers, fenced by host barriers; streams, events, launch phases and ghost bookkeeping are
+// the ones of the RCCL path.
+struct LoopbackGroup
+{
+  std::vector<asm_ctx *>  ranks;
+  std::vector<double>     scalars;
+  std::mutex              m;
+  std::condition_variable cv;
+  int                     waiting = 0, generation = 0;
+  void
+  barrier()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    const int                    gen = generation;
+    if (++waiting == (int)ranks.size())
+      {
+        waiting = 0;
+        ++generation;
+        cv.notify_all();
+      }
+    else
+      cv.wait(lk, [&] { return gen != generation; });
+  }
+};
 
 struct asm_ctx
 {
@@ -47,14 +77,28 @@ struct asm_ctx
   double                   lambda_max = 0., theta = 0., delta = 0.;
   bool                     ev_set     = false;
   ncclComm_t               comm       = nullptr;
+  std::shared_ptr<LoopbackGroup> loop; // testing aid, in place of comm
   double *                 hbuf[4]    = {nullptr, nullptr, nullptr, nullptr}; // send lo/hi, recv lo/hi
   long long                hbuf_size  = 0;
   bool                     external_exchange = false; // testing aid: ghosts are exchanged by asm_debug_exchange_all
+  bool                     debug_two_phase   = false; // testing aid: boundary and interior workgroups in two launches
   // single-round ghost update (update_ghost_values of the tiled kernels): setup.h: build_direct_plan
   asm_direct_message       dmsg[26];
   int                      n_dmsg = 0;
   BoxList                  dsend, drecv;
   double *                 dbuf[2] = {nullptr, nullptr}; // send, receive
+  // Overlap of the ghost exchange with the sweep that produces the vector (tiled kernels, inside
+  // PreconditionChebyshev::vmult/step): the workgroups that produce DoFs a neighbour ghosts run first, the
+  // exchange of the NEW vector then runs on comm_stream beside the remaining workgroups, and the next
+  // sweep only waits for ev_exchanged.
+  hipStream_t              comm_stream  = nullptr;
+  hipEvent_t               ev_boundary  = nullptr, ev_exchanged = nullptr;
+  bool                     overlap      = false;   // available (set by asm_comm_init)
+  bool                     in_cheb      = false;   // inside cheb_run
+  bool                     last_sweep   = false;   // the sweep's result is not read by another sweep of this call
+  bool                     keep_ghosts  = false;   // asm_set_keep_ghosts: vectors are not modified between calls
+  const double *           exchanged_vec = nullptr; // vector whose ghosts an overlapped exchange has filled / is filling
+  bool                     exchange_pending = false; // ... and ctx->stream has not waited for it yet
   // optional per-kernel timing with HIP events on the context's stream
   bool                                           profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[2];
@@ -160,17 +204,37 @@ namespace
   // (include/matrix_free_internal.h:13-47); add = true runs the reverse
   // (import_from_ghosted_array with VectorOperation::add, :49-84) and zeroes
   // the ghost planes afterwards (:86-103).
+  int exchange_loopback(asm_ctx *ctx, double *v, hipStream_t st);
+
   int
   exchange(asm_ctx *ctx, double *v, const bool add)
   {
     if (!multi_rank(ctx) || ctx->external_exchange)
       return ASM_OK;
-    if (ctx->comm == nullptr)
+    if (ctx->comm == nullptr && !ctx->loop)
       {
         ctx->error = "world_size > 1 but asm_comm_init() has not been called";
         return ASM_ERR_INVALID_VALUE;
       }
+    // whatever runs on comm_stream has to be finished before this stream reads the ghosts it fills
+    // or issues another RCCL operation
+    if (ctx->exchange_pending)
+      {
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_exchanged, 0));
+        ctx->exchange_pending = false;
+      }
+    if (!add && ctx->exchanged_vec == v)
+      return ASM_OK; // filled by the overlapped exchange that followed the sweep which produced v
     const DevGrid &g = ctx->g;
+    if (ctx->loop)
+      {
+        if (add || ctx->n_dmsg == 0)
+          {
+            ctx->error = "the loopback group only carries the single-round ghost update";
+            return ASM_ERR_NOT_SUPPORTED;
+          }
+        return exchange_loopback(ctx, v, ctx->stream);
+      }
     if (!add && ctx->n_dmsg > 0)
       {
         // one round: pack all boxes, one grouped send/recv with every neighbour, unpack all boxes
@@ -234,10 +298,29 @@ namespace
   {
     if (multi_rank(ctx))
       {
+        if (ctx->loop)
+          {
+            LoopbackGroup &lg = *ctx->loop;
+            HIP_TRY(hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            lg.scalars[ctx->s.prm.rank] = *ctx->h_scalar;
+            lg.barrier();
+            double sum = 0.;
+            for (const double x : lg.scalars)
+              sum += x;
+            lg.barrier();
+            *out = sum;
+            return ASM_OK;
+          }
         if (ctx->comm == nullptr)
           {
             ctx->error = "world_size > 1 but asm_comm_init() has not been called";
             return ASM_ERR_INVALID_VALUE;
+          }
+        if (ctx->exchange_pending) // one RCCL operation of this communicator at a time
+          {
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_exchanged, 0));
+            ctx->exchange_pending = false;
           }
         NCCL_TRY(ncclAllReduce(ctx->d_scalar, ctx->d_scalar, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
       }
@@ -255,6 +338,109 @@ namespace
     return reduce_scalar(ctx, out);
   }
 
+  // testing aid: the single-round ghost update through the loopback group (host-synchronous)
+  int
+  exchange_loopback(asm_ctx *ctx, double *v, hipStream_t st)
+  {
+    LoopbackGroup &lg = *ctx->loop;
+    vec_boxes(ctx->g, 0, v, ctx->dbuf[0], ctx->dsend, st);
+    HIP_TRY(hipStreamSynchronize(st));
+    lg.barrier(); // every rank has packed
+    for (int i = 0; i < ctx->n_dmsg; ++i)
+      {
+        const asm_direct_message &m = ctx->dmsg[i];
+        if (m.recv_count == 0)
+          continue;
+        const asm_ctx *           pc = lg.ranks[m.peer];
+        const asm_direct_message *pm = nullptr;
+        for (int j = 0; j < pc->n_dmsg; ++j)
+          if (pc->dmsg[j].peer == ctx->s.prm.rank && pc->dmsg[j].offset[0] == -m.offset[0] && pc->dmsg[j].offset[1] == -m.offset[1] &&
+              pc->dmsg[j].offset[2] == -m.offset[2])
+            pm = &pc->dmsg[j];
+        if (pm == nullptr || pm->send_count != m.recv_count)
+          {
+            ctx->error = "loopback exchange: send and receive boxes do not match";
+            return ASM_ERR_INVALID_VALUE;
+          }
+        HIP_TRY(hipMemcpyAsync(ctx->dbuf[1] + m.recv_offset, pc->dbuf[0] + pm->send_offset, m.recv_count * sizeof(double),
+                               hipMemcpyDeviceToDevice, st));
+      }
+    HIP_TRY(hipStreamSynchronize(st));
+    lg.barrier(); // every rank has read its neighbours' send buffers
+    vec_boxes(ctx->g, 1, v, ctx->dbuf[1], ctx->drecv, st);
+    return ASM_OK;
+  }
+
+  // the single-round ghost update of v on comm_stream, started when ev_boundary has fired
+  int
+  exchange_overlapped(asm_ctx *ctx, double *v)
+  {
+    HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_boundary, 0));
+    if (ctx->loop)
+      {
+        const int err = exchange_loopback(ctx, v, ctx->comm_stream);
+        if (err)
+          return err;
+        HIP_TRY(hipEventRecord(ctx->ev_exchanged, ctx->comm_stream));
+        ctx->exchanged_vec    = v;
+        ctx->exchange_pending = true;
+        return ASM_OK;
+      }
+    vec_boxes(ctx->g, 0, v, ctx->dbuf[0], ctx->dsend, ctx->comm_stream);
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < ctx->n_dmsg; ++i)
+      if (ctx->dmsg[i].send_count > 0)
+        NCCL_TRY(ncclSend(ctx->dbuf[0] + ctx->dmsg[i].send_offset, ctx->dmsg[i].send_count, ncclDouble, ctx->dmsg[i].peer, ctx->comm,
+                          ctx->comm_stream));
+    for (int i = ctx->n_dmsg - 1; i >= 0; --i)
+      if (ctx->dmsg[i].recv_count > 0)
+        NCCL_TRY(ncclRecv(ctx->dbuf[1] + ctx->dmsg[i].recv_offset, ctx->dmsg[i].recv_count, ncclDouble, ctx->dmsg[i].peer, ctx->comm,
+                          ctx->comm_stream));
+    NCCL_TRY(ncclGroupEnd());
+    vec_boxes(ctx->g, 1, v, ctx->dbuf[1], ctx->drecv, ctx->comm_stream);
+    HIP_TRY(hipEventRecord(ctx->ev_exchanged, ctx->comm_stream));
+    ctx->exchanged_vec    = v;
+    ctx->exchange_pending = true;
+    return ASM_OK;
+  }
+
+  // launch a tiled sweep; inside cheb_run with several ranks: boundary workgroups, exchange of the
+  // result beside the interior workgroups (unless nobody reads the result's ghosts afterwards)
+  template <typename Launch>
+  int
+  launch_tiled_sweep(asm_ctx *ctx, TiledArgs &a, const Launch &launch, bool *ok)
+  {
+    if (a.dst == ctx->exchanged_vec)
+      ctx->exchanged_vec = nullptr; // overwritten: its ghosts are no longer current
+    const bool ov = ctx->overlap && ctx->in_cheb && !ctx->external_exchange && !(ctx->last_sweep && !ctx->keep_ghosts);
+    for (int d = 0; d < 3; ++d)
+      for (int f = 0; f < 2; ++f)
+        a.iface[d][f] = ctx->s.face[d][f] == FACE_INTERFACE;
+    if (!ov && ctx->debug_two_phase)
+      {
+        a.phase = 1;
+        *ok     = launch(a);
+        a.phase = 2;
+        *ok     = *ok && launch(a);
+        return ASM_OK;
+      }
+    if (!ov)
+      {
+        a.phase = 0;
+        *ok     = launch(a);
+        return ASM_OK;
+      }
+    a.phase = 1;
+    *ok     = launch(a);
+    if (!*ok)
+      return ASM_OK;
+    HIP_TRY(hipEventRecord(ctx->ev_boundary, ctx->stream));
+    a.phase = 2;
+    *ok     = launch(a);
+    // enqueued behind the interior launch on the host, beside it on the device
+    return exchange_overlapped(ctx, a.dst);
+  }
+
   // ---- sweeps --------------------------------------------------------------
   // dst = A src (OP_PLAIN) or dst = b - A src with identity rows on constrained
   // DoFs (OP_RESIDUAL); src's ghosts are updated here.
@@ -270,7 +456,10 @@ namespace
         // generic (quadrature-point Jacobian) kernel below
         TiledArgs a{mode, src, dst, b, nullptr, nullptr, 0., 0.};
         prof_mark(ctx, 0, true);
-        const bool ok = laplace_tiled(ctx->g, ctx->op, a, ctx->stream);
+        bool ok = false;
+        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t) { return laplace_tiled(ctx->g, ctx->op, t, ctx->stream); }, &ok);
+        if (err)
+          return err;
         if (ok)
           {
             prof_mark(ctx, 0, false);
@@ -278,6 +467,8 @@ namespace
           }
         ctx->prof_used[0] -= 0; // begin event is simply re-recorded by the generic launch
       }
+    if (dst == ctx->exchanged_vec)
+      ctx->exchanged_vec = nullptr;
     HIP_TRY(hipMemsetAsync(dst, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     prof_mark(ctx, 0, true);
     const bool ok = laplace_generic(ctx->g, ctx->op, src, dst, false, ctx->stream);
@@ -327,7 +518,10 @@ namespace
       {
         TiledArgs a{mode, src, dst, nullptr, x, x_old, f1, f2};
         prof_mark(ctx, 1, true);
-        const bool ok = fdm_tiled(ctx->g, ctx->f, a, ctx->stream);
+        bool ok = false;
+        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t) { return fdm_tiled(ctx->g, ctx->f, t, ctx->stream); }, &ok);
+        if (err)
+          return err;
         prof_mark(ctx, 1, false);
         if (!ok)
           {
@@ -337,6 +531,8 @@ namespace
         return ASM_OK;
       }
     double *t = (mode == PC_PLAIN) ? dst : ctx->T;
+    if (dst == ctx->exchanged_vec)
+      ctx->exchanged_vec = nullptr;
     HIP_TRY(hipMemsetAsync(t, 0, n * sizeof(double), ctx->stream));
     prof_mark(ctx, 1, true);
     const bool ok = fdm_generic(ctx->g, ctx->f, src, t, ctx->stream);
@@ -383,11 +579,30 @@ namespace
     double *     A = dst, *S = ctx->S, *R = ctx->R;
     double *     cur, *prev; // cur holds x_j, prev holds x_{j-1}
     int          err;
+    // sweeps of this call may exchange their results beside their own interior work
+    struct Scope
+    {
+      asm_ctx *c;
+      explicit Scope(asm_ctx *ctx)
+        : c(ctx)
+      {
+        c->in_cheb    = true;
+        c->last_sweep = false;
+        if (!c->keep_ghosts)
+          c->exchanged_vec = nullptr;
+      }
+      ~Scope()
+      {
+        c->in_cheb    = false;
+        c->last_sweep = false;
+      }
+    } scope(ctx);
     if (zero_start)
       {
         // the final iterate lands in A if the first one goes to A for odd k, to S for even k
-        cur = (k_total % 2) ? A : S;
-        err = pc_apply(ctx, PC_FIRST, cur, const_cast<double *>(b), nullptr, nullptr, 0., 1. / theta);
+        cur             = (k_total % 2) ? A : S;
+        ctx->last_sweep = k_total == 1;
+        err             = pc_apply(ctx, PC_FIRST, cur, const_cast<double *>(b), nullptr, nullptr, 0., 1. / theta);
         if (err)
           return err;
         prev = nullptr;
@@ -398,7 +613,10 @@ namespace
         if (err)
           return err;
         if (k_total == 1)
-          return pc_apply(ctx, PC_STEP1, A, R, A, nullptr, 1., 1. / theta);
+          {
+            ctx->last_sweep = true;
+            return pc_apply(ctx, PC_STEP1, A, R, A, nullptr, 1., 1. / theta);
+          }
         err = pc_apply(ctx, PC_STEP1, S, R, A, nullptr, 1., 1. / theta);
         if (err)
           return err;
@@ -415,6 +633,7 @@ namespace
         err  = op_apply(ctx, OP_RESIDUAL, R, cur, b);
         if (err)
           return err;
+        ctx->last_sweep = k == k_total - 1;
         if (prev == nullptr)
           {
             // x_0 = 0: x_2 = (1 + f1) x_1 + f2 t
@@ -432,7 +651,18 @@ namespace
           return err;
       }
     if (cur != A)
-      HIP_TRY(hipMemcpyAsync(A, cur, ctx->s.n_alloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      {
+        if (ctx->exchange_pending) // the copy includes the ghost planes
+          {
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_exchanged, 0));
+            ctx->exchange_pending = false;
+          }
+        HIP_TRY(hipMemcpyAsync(A, cur, ctx->s.n_alloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        if (ctx->exchanged_vec == cur)
+          ctx->exchanged_vec = A;
+        else if (ctx->exchanged_vec == A)
+          ctx->exchanged_vec = nullptr;
+      }
     return ASM_OK;
   }
 
@@ -720,6 +950,13 @@ asm_destroy(asm_ctx *ctx)
   if (!ctx)
     return;
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm_stream)
+    {
+      (void)hipStreamSynchronize(ctx->comm_stream);
+      (void)hipEventDestroy(ctx->ev_boundary);
+      (void)hipEventDestroy(ctx->ev_exchanged);
+      (void)hipStreamDestroy(ctx->comm_stream);
+    }
   if (ctx->comm)
     ncclCommDestroy(ctx->comm);
   for (int k = 0; k < 2; ++k)
@@ -746,12 +983,51 @@ asm_comm_unique_id(char id[128])
   return ASM_OK;
 }
 
+static int
+setup_overlap(asm_ctx *ctx)
+{
+  if (ctx->s.kernel == ASM_KERNEL_TILED && ctx->n_dmsg > 0 && std::getenv("ASM_NO_OVERLAP") == nullptr && !ctx->overlap)
+    {
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_boundary, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_exchanged, hipEventDisableTiming));
+      ctx->overlap = true;
+    }
+  return ASM_OK;
+}
+
+// testing aid: ctxs[r] = rank r of n; afterwards every rank must be driven by its own host thread
+int
+asm_debug_loopback_init(asm_ctx **ctxs, int n)
+{
+  auto lg = std::make_shared<LoopbackGroup>();
+  lg->ranks.assign(ctxs, ctxs + n);
+  lg->scalars.assign(n, 0.);
+  for (int r = 0; r < n; ++r)
+    {
+      asm_ctx *ctx = ctxs[r];
+      if (ctx->s.prm.rank != r || ctx->s.prm.world_size != n)
+        {
+          ctx->error = "asm_debug_loopback_init: ctxs[r] must be rank r of n";
+          return ASM_ERR_INVALID_VALUE;
+        }
+      ctx->loop     = lg;
+      const int err = setup_overlap(ctx);
+      if (err)
+        return err;
+    }
+  return ASM_OK;
+}
+
 int
 asm_comm_init(asm_ctx *ctx, const char id[128])
 {
   ncclUniqueId uid;
   std::memcpy(&uid, id, 128);
   NCCL_TRY(ncclCommInitRank(&ctx->comm, ctx->s.prm.world_size, uid, ctx->s.prm.rank));
+  const int err = setup_overlap(ctx);
+  if (err)
+    return err;
   if (ctx->s.prm.precond_type == ASM_PRECOND_DIAGONAL)
     return asm_op_inverse_diagonal(ctx, ctx->inv_diag);
   return ASM_OK;
@@ -774,6 +1050,10 @@ int
 asm_vector_free(asm_ctx *ctx, double *v)
 {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream)
+    HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
+  if (v == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
   HIP_TRY(hipFree(v));
   return ASM_OK;
 }
@@ -784,6 +1064,11 @@ asm_vector_import(asm_ctx *ctx, double *dev, const double *host_owned)
   const DevGrid &g = ctx->g;
   const int      lo[3] = {0, 0, 0}, size[3] = {g.own_hi[0] + 1, g.own_hi[1] + 1, g.own_hi[2] + 1};
   double *       buf   = nullptr;
+  if (ctx->comm_stream)
+    HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
+  ctx->exchange_pending = false;
+  if (dev == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
   HIP_TRY(hipMalloc((void **)&buf, ctx->s.n_owned * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(buf, host_owned, ctx->s.n_owned * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemsetAsync(dev, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
@@ -822,6 +1107,8 @@ asm_compress_add(asm_ctx *ctx, double *v)
 int
 asm_op_vmult(asm_ctx *ctx, double *dst, const double *src)
 {
+  if (!ctx->keep_ghosts)
+    ctx->exchanged_vec = nullptr;
   return op_apply(ctx, OP_PLAIN, dst, const_cast<double *>(src), nullptr);
 }
 
@@ -844,6 +1131,8 @@ asm_op_inverse_diagonal(asm_ctx *ctx, double *out)
 int
 asm_precond_vmult(asm_ctx *ctx, double *dst, const double *src)
 {
+  if (!ctx->keep_ghosts)
+    ctx->exchanged_vec = nullptr;
   return pc_apply(ctx, PC_PLAIN, dst, const_cast<double *>(src), nullptr, nullptr, 0., 1.);
 }
 
@@ -871,6 +1160,7 @@ asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max)
   const asm_params &prm = ctx->s.prm;
   const long long   n   = ctx->s.n_alloc;
   int               alg = prm.ev_algorithm;
+  ctx->exchanged_vec    = nullptr; // the vectors of the estimate are also written by plain vector kernels
   if (alg == ASM_EV_AUTO)
     {
       // SymmetryType, include/matrix_free.h:896-904 and precondition.templates.h:113-114
@@ -1019,6 +1309,17 @@ int
 asm_synchronize(asm_ctx *ctx)
 {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream)
+    HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
+  return ASM_OK;
+}
+
+int
+asm_set_keep_ghosts(asm_ctx *ctx, int on)
+{
+  ctx->keep_ghosts = on != 0;
+  if (!ctx->keep_ghosts)
+    ctx->exchanged_vec = nullptr;
   return ASM_OK;
 }
 
@@ -1069,6 +1370,15 @@ int
 asm_debug_external_exchange(asm_ctx *ctx, int on)
 {
   ctx->external_exchange = on != 0;
+  return ASM_OK;
+}
+
+// the tiled sweeps as two launches (workgroups next to interface faces, then the others), as the
+// overlapped exchange launches them, but without an exchange in between
+int
+asm_debug_two_phase(asm_ctx *ctx, int on)
+{
+  ctx->debug_two_phase = on != 0;
   return ASM_OK;
 }
 

@@ -33,6 +33,11 @@ namespace asmamd
     const double *x;     // PC_STEP1 / PC_UPDATE
     const double *x_old; // PC_UPDATE
     double        f1, f2;
+    // overlap of the ghost exchange with the sweep: 0 = all workgroups, 1 = only those that produce
+    // DoFs a neighbouring rank ghosts (cells 0 and nc-1 of a direction whose face is an interface),
+    // 2 = the others
+    int phase       = 0;
+    int iface[3][2] = {{0, 0}, {0, 0}, {0, 0}};
   };
   bool laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st);
   bool fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st);

@@ -138,6 +138,17 @@ namespace asmamd
       return xcd * (n >> 3) + min(xcd, n & 7) + idx;
     }
 
+    // does this workgroup take part in the launch (TiledArgs::phase)?
+    __device__ __forceinline__ bool
+    workgroup_in_phase(const TiledArgs &a, const Tiling &tl, const int tx, const int ty, const int zc)
+    {
+      if (a.phase == 0)
+        return true;
+      const bool bnd = (a.iface[0][0] && tx == 0) || (a.iface[0][1] && tx == tl.ntx - 1) || (a.iface[1][0] && ty == 0) ||
+                       (a.iface[1][1] && ty == tl.nty - 1) || (a.iface[2][0] && zc == 0) || (a.iface[2][1] && zc == tl.nzc - 1);
+      return (a.phase == 1) == bnd;
+    }
+
     // is cell c (local coordinate, may be -1) computed by this rank?
     __device__ __forceinline__ bool
     cell_computable(const DevGrid &g, const int d, const int c)
@@ -810,6 +821,8 @@ namespace asmamd
 
       const int b  = xcd_remap(blockIdx.x, gridDim.x);
       const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
+      if (!workgroup_in_phase(a, tl, tx, ty, zc))
+        return;
       const int X0 = tx * OX - 1, Y0 = ty * OY - 1; // tile cell (0,0)
 
       CellLane c;
@@ -1104,6 +1117,8 @@ namespace asmamd
 
       const int b  = xcd_remap(blockIdx.x, gridDim.x);
       const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
+      if (!workgroup_in_phase(a, tl, tx, ty, zc))
+        return;
       const int X0 = tx * OX - 1, Y0 = ty * OY - 1;
 
       CellLane c;

@@ -267,6 +267,14 @@ int asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_m
 /* timing helper for benchmarks: runs `reps` back-to-back calls of one entry
  * point between two HIP events on the context's stream and returns the
  * elapsed milliseconds.  what: 0 op_vmult, 1 precond_vmult, 2 cheb_vmult, 3 cheb_step */
+/* Promise of the caller: between two calls vectors are modified only through this library
+ * (asm_vector_import, vmult, step).  A vector produced by the last sweep of a Chebyshev call then
+ * keeps the ghost values its overlapped exchange has filled, and the next call does not exchange
+ * it again.  Off by default: vmult/step then update the ghosts of their input themselves, as
+ * LinearAlgebra::distributed::Vector::update_ghost_values does inside MFRunner::loop
+ * (include/matrix_free_internal.h:321-324). */
+int asm_set_keep_ghosts(asm_ctx *ctx, int on);
+
 int asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms);
 
 /* ----- testing aids ---------------------------------------------------------
@@ -278,6 +286,13 @@ int asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *
  * (include/matrix_free_internal.h:309-359; add == 0: update_ghost_values,
  * add != 0: compress(add)) for vecs[r] of ctxs[r], r = rank = 0..n-1, at once. */
 int asm_debug_external_exchange(asm_ctx *ctx, int on);
+/* tiled sweeps as the overlapped exchange launches them (boundary workgroups, then interior
+ * workgroups), without the exchange */
+int asm_debug_two_phase(asm_ctx *ctx, int on);
+/* ctxs[r] = rank r of n in this process; afterwards every rank is driven by its own host thread and
+ * vmult/step/estimate run their multi-rank control flow (streams, events, launch phases, ghost
+ * bookkeeping) with device copies + host barriers in place of RCCL */
+int asm_debug_loopback_init(asm_ctx **ctxs, int n);
 int asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add);
 
 #ifdef __cplusplus
