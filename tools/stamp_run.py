@@ -26,11 +26,13 @@ n = 10
 for _ in range(n):
     ctx.cheb_step(x, b)
 lib.asm_debug_stamps(ctx.handle, out, 1)
-names_l = ["(loop overhead)", "wait for staged rows", "LDS read, x + y sweeps", "gather+ops issue, 2 transposes", "", "", "z sweeps", "merge x/z (lane shift)",
-           "stores issue", "", "z sweeps (LDS write wait) + y slot write", "barrier", "y slot read", "wait for update operands"]
-names_f = ["(loop overhead)", "wait for staged rows", "LDS read, tables, weights, x + z fwd", "gather+ops issue, transpose", "y fwd, scale, y bwd", "transpose",
-           "z + x bwd, weights", "merge x/z (lane shift)", "stores issue", "", "bwd sweeps + y slot write", "barrier", "y slot read", "wait for update operands"]
-layers = 17 * n
+names_l = ["(loop overhead)", "LDS image read", "x + z fwd sweeps, DMA requests", "transpose", "y sweeps, scaling, operand requests", "transpose",
+           "z + x bwd sweeps", "merge x/z (lane shift)", "fused update, stores issue", "", "y slot write", "barrier", "y slot read",
+           "wait: staged rows + operands"]
+names_f = ["(loop overhead)", "LDS image read, tables, weights", "x + z fwd sweeps", "transpose", "y sweeps, scaling, DMA + operand requests",
+           "transpose", "z + x bwd sweeps, weights", "merge x/z (lane shift)", "fused update, stores issue", "", "y slot write", "barrier",
+           "y slot read", "wait: staged rows + operands"]
+layers = 11 * n  # 8 z chunks of 10 layers + halo layer
 for title, base, names in (("Laplace (OP_RESIDUAL)", 0, names_l), ("FDM (PC_STEP1)", 16, names_f)):
     tot = sum(out[base + i] for i in range(16))
     print(title)
