@@ -87,6 +87,7 @@ struct asm_ctx
   int                      n_dmsg = 0;
   BoxList                  dsend, drecv;
   double *                 dbuf[2] = {nullptr, nullptr}; // send, receive
+  double *                 patch_tmp = nullptr; // generic FDM: n_cells * m^3 patch results (kernels.h: fdm_generic)
   // Overlap of the ghost exchange with the sweep that produces the vector (tiled kernels, inside
   // PreconditionChebyshev::vmult/step): the workgroups that produce DoFs a neighbour ghosts run first, the
   // exchange of the NEW vector then runs on comm_stream beside the remaining workgroups, and the next
@@ -533,9 +534,10 @@ namespace
     double *t = (mode == PC_PLAIN) ? dst : ctx->T;
     if (dst == ctx->exchanged_vec)
       ctx->exchanged_vec = nullptr;
-    HIP_TRY(hipMemsetAsync(t, 0, n * sizeof(double), ctx->stream));
+    if (ctx->patch_tmp == nullptr)
+      HIP_TRY(hipMemsetAsync(t, 0, n * sizeof(double), ctx->stream));
     prof_mark(ctx, 1, true);
-    const bool ok = fdm_generic(ctx->g, ctx->f, src, t, ctx->stream);
+    const bool ok = fdm_generic(ctx->g, ctx->f, src, t, ctx->patch_tmp, ctx->stream);
     prof_mark(ctx, 1, false);
     if (!ok)
       {
@@ -873,6 +875,24 @@ asm_create(const asm_params *p, asm_ctx **out)
   ctx->allocs.push_back(ctx->R);
   ctx->allocs.push_back(ctx->T);
   ctx->allocs.push_back(ctx->S);
+  // (restricted additive Schwarz keeps the atomics: only a patch's own DoFs have a non-zero weight,
+  // so a sixth of the entries is added and the atomic form is the faster one - measured)
+  if (s.prm.precond_type == ASM_PRECOND_FDM && (s.kernel != ASM_KERNEL_TILED || !tiled_kernels_available()) &&
+      s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_FDM_ATOMICS") == nullptr)
+    {
+      // patch results of the generic FDM sweep; without it (allocation failure) the sweep adds with atomics
+      const size_t bytes = (size_t)s.g.nc[0] * s.g.nc[1] * s.g.nc[2] * s.m * s.m * s.m * sizeof(double);
+      if (hipMalloc((void **)&ctx->patch_tmp, bytes) == hipSuccess)
+        {
+          ctx->allocs.push_back(ctx->patch_tmp);
+          ctx->data_bytes += bytes;
+        }
+      else
+        {
+          (void)hipGetLastError();
+          ctx->patch_tmp = nullptr;
+        }
+    }
   if (hipMalloc((void **)&ctx->d_scalar, 64) != hipSuccess || hipHostMalloc((void **)&ctx->h_scalar, 64) != hipSuccess)
     {
       ctx->error = "allocation of reduction scalars failed";

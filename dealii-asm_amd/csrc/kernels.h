@@ -9,7 +9,10 @@ namespace asmamd
 {
   // ---- generic sweeps (kernels_generic.hip): dst must be zeroed by the caller,
   //      contributions are added with fp64 atomics
-  bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, hipStream_t st);
+  // tmp == nullptr: contributions are added to dst with atomics (dst zeroed by the caller);
+  // otherwise tmp holds n_cells * m^3 doubles: patch results are stored there and summed per DoF
+  // by a second kernel that writes every stored entry of dst (no zeroing, no atomics)
+  bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, hipStream_t st);
   bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st);
 
   // ---- tiled owner-computes sweeps (kernels_tiled.hip), degree 4, n_overlap 1

@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 namespace asmamd
 {
   namespace
@@ -73,7 +75,10 @@ namespace asmamd
         u[i] = t[i];
     }
 
-    template <int M>
+    // STORE = false: contributions are added to dst with atomics (dst zeroed by the caller);
+    // STORE = true:  the weighted patch result goes to tmp[cell][k][j][i] (every entry, zero where the
+    //                entry does not contribute) and fdm_gather_kernel sums the patches per DoF
+    template <int M, bool STORE>
     __global__ void __launch_bounds__(BLOCK)
     fdm_generic_kernel(const DevGrid g, const DevFdm f, const double *__restrict__ src, double *__restrict__ dst)
     {
@@ -162,7 +167,14 @@ namespace asmamd
           const double lyz = Qs[lc][1][C::M2 + a] + Qs[lc][2][C::M2 + b];
 #pragma unroll
           for (int i = 0; i < M; ++i)
-            u[i] = u[i] / (Qs[lc][0][C::M2 + i] + lyz);
+            {
+              // reciprocal with two Newton steps (full double precision, a fifth of an IEEE division)
+              const double sm = Qs[lc][0][C::M2 + i] + lyz;
+              double       r  = __builtin_amdgcn_rcp(sm);
+              r               = fma(fma(-sm, r, 1.0), r, r);
+              r               = fma(fma(-sm, r, 1.0), r, r);
+              u[i] *= r;
+            }
           sweep_bwd<M>(Qs[lc][0], u);
 #pragma unroll
           for (int i = 0; i < M; ++i)
@@ -191,7 +203,17 @@ namespace asmamd
           const int    I = o0 + a, J = o1 + b;
           const bool   exy = g.exists(0, I) && g.exists(1, J);
           const double wxy = f.w_post[0][(c3[0] + 1) * M + a] * f.w_post[1][(c3[1] + 1) * M + b];
-          if (exy && wxy != 0.)
+          if (STORE)
+            {
+              double *t = dst + (long long)cell * C::M3 + b * M + a;
+#pragma unroll
+              for (int k = 0; k < M; ++k)
+                {
+                  const double w = wxy * f.w_post[2][(c3[2] + 1) * M + k];
+                  t[k * C::M2]   = (exy && g.exists(2, o2 + k) && w != 0.) ? u[k] * w : 0.;
+                }
+            }
+          else if (exy && wxy != 0.)
             {
               const long long base = g.store_index(0, I) * g.stride[0] + g.store_index(1, J) * g.stride[1];
 #pragma unroll
@@ -203,6 +225,61 @@ namespace asmamd
                     unsafeAtomicAdd(&dst[base + g.store_index(2, K) * g.stride[2]], u[k] * w);
                 }
             }
+        }
+    }
+
+    // Sum of the patch results per DoF (second half of the scatter-add of include/matrix_free.h:
+    // 1023-1162 without atomics): one thread per stored DoF (ghost planes included: they carry this
+    // rank's contributions to DoFs of its neighbours until compress(add)); along every direction the
+    // DoF lies in the patches of at most ceil(m / p) cells.
+    struct GatherDir
+    {
+      int n;
+      int cell[4], idx[4];
+    };
+    __device__ __forceinline__ void
+    gather_candidates(const DevGrid &g, const DevFdm &f, const int d, const int I, GatherDir &out)
+    {
+      const int np = g.nc[d] * g.p, m = f.m;
+      out.n        = 0;
+      for (int s = (g.wrap[d] ? -1 : 0); s <= (g.wrap[d] ? 1 : 0); ++s)
+        {
+          const int Is = I + s * np, t = Is - f.origin_add;
+          // largest cell whose patch origin is not beyond Is, then downwards while the patch still covers Is
+          int c = t >= 0 ? t / f.origin_mul : -((-t + f.origin_mul - 1) / f.origin_mul);
+          for (; Is - (f.origin_mul * c + f.origin_add) < m; --c)
+            if (c >= 0 && c < g.nc[d] && out.n < 4)
+              {
+                out.cell[out.n] = c;
+                out.idx[out.n]  = Is - (f.origin_mul * c + f.origin_add);
+                ++out.n;
+              }
+        }
+    }
+
+    __global__ void __launch_bounds__(BLOCK)
+    fdm_gather_kernel(const DevGrid g, const DevFdm f, const double *__restrict__ tmp, double *__restrict__ dst)
+    {
+      const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1, sz = g.ext_hi[2] - g.ext_lo[2] + 1;
+      const long long n  = (long long)sx * sy * sz;
+      const int       m = f.m, m2 = m * m;
+      const long long m3 = (long long)m2 * m;
+      for (long long e = blockIdx.x * (long long)BLOCK + threadIdx.x; e < n; e += (long long)gridDim.x * BLOCK)
+        {
+          const int si = (int)(e % sx), sj = (int)((e / sx) % sy), sk = (int)(e / ((long long)sx * sy));
+          GatherDir cx, cy, cz;
+          gather_candidates(g, f, 0, si + g.ext_lo[0], cx);
+          gather_candidates(g, f, 1, sj + g.ext_lo[1], cy);
+          gather_candidates(g, f, 2, sk + g.ext_lo[2], cz);
+          double sum = 0.;
+          for (int kz = 0; kz < cz.n; ++kz)
+            for (int ky = 0; ky < cy.n; ++ky)
+              for (int kx = 0; kx < cx.n; ++kx)
+                {
+                  const long long cell = cx.cell[kx] + (long long)g.nc[0] * (cy.cell[ky] + (long long)g.nc[1] * cz.cell[kz]);
+                  sum += tmp[cell * m3 + cz.idx[kz] * m2 + cy.idx[ky] * m + cx.idx[kx]];
+                }
+          dst[si * g.stride[0] + sj * g.stride[1] + sk * g.stride[2]] = sum;
         }
     }
 
@@ -552,30 +629,38 @@ namespace asmamd
   // -----------------------------------------------------------------------
   template <int M>
   static void
-  launch_fdm(const DevGrid &g, const DevFdm &f, const double *src, double *dst, hipStream_t st)
+  launch_fdm(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, hipStream_t st)
   {
     const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
     const int blocks = (ncells + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
-    hipLaunchKernelGGL(fdm_generic_kernel<M>, dim3(blocks), dim3(BLOCK), 0, st, g, f, src, dst);
+    if (tmp == nullptr)
+      {
+        hipLaunchKernelGGL((fdm_generic_kernel<M, false>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, dst);
+        return;
+      }
+    hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, tmp);
+    const long long n = (long long)(g.ext_hi[0] - g.ext_lo[0] + 1) * (g.ext_hi[1] - g.ext_lo[1] + 1) * (g.ext_hi[2] - g.ext_lo[2] + 1);
+    const long long gb = std::min<long long>((n + BLOCK - 1) / BLOCK, 1 << 20);
+    hipLaunchKernelGGL(fdm_gather_kernel, dim3((unsigned)gb), dim3(BLOCK), 0, st, g, f, tmp, dst);
   }
 
   bool
-  fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, hipStream_t st)
+  fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, hipStream_t st)
   {
     switch (f.m)
       {
-        case 2: launch_fdm<2>(g, f, src, dst, st); break;
-        case 3: launch_fdm<3>(g, f, src, dst, st); break;
-        case 4: launch_fdm<4>(g, f, src, dst, st); break;
-        case 5: launch_fdm<5>(g, f, src, dst, st); break;
-        case 6: launch_fdm<6>(g, f, src, dst, st); break;
-        case 7: launch_fdm<7>(g, f, src, dst, st); break;
-        case 8: launch_fdm<8>(g, f, src, dst, st); break;
-        case 9: launch_fdm<9>(g, f, src, dst, st); break;
-        case 10: launch_fdm<10>(g, f, src, dst, st); break;
-        case 11: launch_fdm<11>(g, f, src, dst, st); break;
-        case 12: launch_fdm<12>(g, f, src, dst, st); break;
-        case 13: launch_fdm<13>(g, f, src, dst, st); break;
+        case 2: launch_fdm<2>(g, f, src, dst, tmp, st); break;
+        case 3: launch_fdm<3>(g, f, src, dst, tmp, st); break;
+        case 4: launch_fdm<4>(g, f, src, dst, tmp, st); break;
+        case 5: launch_fdm<5>(g, f, src, dst, tmp, st); break;
+        case 6: launch_fdm<6>(g, f, src, dst, tmp, st); break;
+        case 7: launch_fdm<7>(g, f, src, dst, tmp, st); break;
+        case 8: launch_fdm<8>(g, f, src, dst, tmp, st); break;
+        case 9: launch_fdm<9>(g, f, src, dst, tmp, st); break;
+        case 10: launch_fdm<10>(g, f, src, dst, tmp, st); break;
+        case 11: launch_fdm<11>(g, f, src, dst, tmp, st); break;
+        case 12: launch_fdm<12>(g, f, src, dst, tmp, st); break;
+        case 13: launch_fdm<13>(g, f, src, dst, tmp, st); break;
         default: return false;
       }
     return true;
