@@ -451,7 +451,7 @@ namespace
     int err = exchange(ctx, src, false);
     if (err)
       return err;
-    if (ctx->s.kernel == ASM_KERNEL_TILED)
+    if (ctx->s.laplace_tiled)
       {
         // the tiled Laplace kernel covers Cartesian geometry; deformed cells take the
         // generic (quadrature-point Jacobian) kernel below
@@ -515,7 +515,7 @@ namespace
     int err = exchange(ctx, src, false);
     if (err)
       return err;
-    if (ctx->s.kernel == ASM_KERNEL_TILED)
+    if (ctx->s.fdm_tiled)
       {
         TiledArgs a{mode, src, dst, nullptr, x, x_old, f1, f2};
         prof_mark(ctx, 1, true);
@@ -877,8 +877,7 @@ asm_create(const asm_params *p, asm_ctx **out)
   ctx->allocs.push_back(ctx->S);
   // (restricted additive Schwarz keeps the atomics: only a patch's own DoFs have a non-zero weight,
   // so a sixth of the entries is added and the atomic form is the faster one - measured)
-  if (s.prm.precond_type == ASM_PRECOND_FDM && (s.kernel != ASM_KERNEL_TILED || !tiled_kernels_available()) &&
-      s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_FDM_ATOMICS") == nullptr)
+  if (s.prm.precond_type == ASM_PRECOND_FDM && !s.fdm_tiled && s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_FDM_ATOMICS") == nullptr)
     {
       // patch results of the generic FDM sweep; without it (allocation failure) the sweep adds with atomics
       const size_t bytes = (size_t)s.g.nc[0] * s.g.nc[1] * s.g.nc[2] * s.m * s.m * s.m * sizeof(double);

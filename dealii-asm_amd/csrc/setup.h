@@ -106,6 +106,7 @@ namespace asmamd
     int        m;      // patch size 1-D
     int        halo_lo, halo_hi; // ghost planes below plane 0 / from plane nc*p upwards on interface faces
     int        kernel; // asm_kernel_variant in use
+    bool       fdm_tiled = false, laplace_tiled = false; // which sweeps of a tiled context run on the tiled kernels
 
     // extended cell box [-1, nc]^3 (halo cells for owner-computes kernels)
     int ence[3]; // nc + 2
@@ -227,15 +228,20 @@ namespace asmamd
       }
 
     // ---- kernel family
+    // the tiled FDM sweep covers degree 4 cell patches with n_overlap 1, the tiled Laplace sweep degree 4
+    // on Cartesian cells; a context uses each of them where it applies and the generic kernel otherwise
     s.kernel = prm.kernel_variant;
-    const bool tiled_ok = (!vertex && prm.n_overlap == 1 && p == 4);
+    const bool fdm_ok = (!vertex && prm.n_overlap == 1 && p == 4), laplace_ok = (p == 4 && prm.geometry == ASM_GEOM_CARTESIAN);
+    const bool tiled_ok = fdm_ok || laplace_ok;
     if (s.kernel == ASM_KERNEL_AUTO)
       s.kernel = (tiled_ok && tiled_kernels_available()) ? ASM_KERNEL_TILED : ASM_KERNEL_GENERIC;
     if (s.kernel == ASM_KERNEL_TILED && !tiled_ok)
       {
-        s.error = "tiled kernels exist for degree 4, n_overlap 1, element-centric patches only";
+        s.error = "tiled kernels exist for degree 4 only: FDM for n_overlap 1 element-centric patches, Laplace for Cartesian cells";
         return false;
       }
+    s.fdm_tiled     = s.kernel == ASM_KERNEL_TILED && fdm_ok;
+    s.laplace_tiled = s.kernel == ASM_KERNEL_TILED && laplace_ok;
 
     DevGrid &g = s.g;
     g.p        = p;

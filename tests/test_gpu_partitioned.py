@@ -168,3 +168,42 @@ def test_multi_rank_control_flow_loopback(world, n_cells, boundary, degree, keep
     assert np.abs(y_out - y_ref).max() < TOL * np.abs(y_ref).max()
     for c in ranks + [single]:
         c.close()
+
+
+@pytest.mark.parametrize("what", ["op", "precond"])
+@pytest.mark.parametrize("n_overlap,element_centric", [(2, True), (1, False)])
+def test_mixed_context_partitioned(what, n_overlap, element_centric):
+    """degree 4 on Cartesian cells with 7^3 patches: tiled Laplace sweep + generic FDM sweep in one
+    context, whose ghost layout (p planes below every block) serves both"""
+    pkg = load_package()
+    kw = dict(degree=4, n_cells=(6, 6, 8), boundary="dirichlet", precond="FDM", n_overlap=n_overlap, element_centric=element_centric,
+              weighting="post")
+    single = pkg.Context(**kw)
+    assert single.kernel_variant() == "tiled"
+    npd = [4 * 6 + 1, 4 * 6 + 1, 4 * 8 + 1]
+    rng = np.random.default_rng(17)
+    xg = rng.standard_normal((npd[2], npd[1], npd[0]))
+    apply_ = {"op": lambda c, d, s: c.op_vmult(d, s), "precond": lambda c, d, s: c.precond_vmult(d, s)}[what]
+    xs, ys = single.vector(xg.reshape(-1)), single.vector()
+    apply_(single, ys, xs)
+    ref = ys.get().reshape(xg.shape)
+    world = 4
+    ranks = [pkg.Context(rank=r, world_size=world, **kw) for r in range(world)]
+    src, dst = [], []
+    for c in ranks:
+        c.external_exchange(True)
+        sl = owned_slices(c.layout, npd)
+        src.append(c.vector(np.ascontiguousarray(xg[sl]).reshape(-1)))
+        dst.append(c.vector())
+    pkg.exchange_all(ranks, src, add=False)
+    for c, d, s in zip(ranks, dst, src):
+        apply_(c, d, s)
+    if what == "precond":  # the generic FDM sweep leaves contributions in the ghost planes
+        pkg.exchange_all(ranks, dst, add=True)
+    out = np.full_like(ref, np.nan)
+    for c, d in zip(ranks, dst):
+        sl = owned_slices(c.layout, npd)
+        out[sl] = d.get().reshape([c.layout.owned_size[k] for k in (2, 1, 0)])
+    assert np.abs(out - ref).max() < TOL * np.abs(ref).max()
+    for c in ranks + [single]:
+        c.close()
