@@ -95,3 +95,34 @@ def test_tile_and_chunk_edges(pkg, nc, bc, extent):
         xv = ctx.vector(x0)
         ctx.cheb_step(xv, x)
         assert rel(xv.get(), cheb.step(x0, src)) < TOL
+
+
+@pytest.mark.parametrize(
+    "nc,bc",
+    [
+        ((1, 1, 1), "dirichlet"),
+        ((2, 1, 1), "dirichlet"),
+        ((1, 1, 3), ["neumann", "dirichlet", "dirichlet"]),
+        ((2, 2, 2), "periodic"),
+        ((12, 1, 1), "dirichlet"),
+        ((1, 8, 1), "neumann"),
+    ],
+)
+def test_tiny_meshes(pkg, nc, bc):
+    """fewer cells than a tile, a wave or a z chunk holds"""
+    mesh, ctx = make_pair(pkg, nc, 4, bc, "cartesian", kernel="tiled", weighting="post", cheb_degree=2)
+    with ctx:
+        rng = np.random.default_rng(3)
+        src = rng.uniform(-1, 1, mesh.n_dofs)
+        x, y = ctx.vector(src), ctx.vector()
+        op, prec = orc.LaplaceOperator(mesh), orc.ASPoissonPreconditioner(mesh, 1, "post")
+        ctx.op_vmult(y, x)
+        assert rel(y.get(), op.vmult(src)) < TOL
+        ctx.precond_vmult(y, x)
+        assert rel(y.get(), prec.vmult(src)) < TOL
+        ctx.set_eigenvalue(1.9)
+        cheb = orc.Chebyshev(op, prec, degree=2, lambda_max=1.9)
+        x0 = rng.uniform(-1, 1, mesh.n_dofs)
+        xv = ctx.vector(x0)
+        ctx.cheb_step(xv, x)
+        assert rel(xv.get(), cheb.step(x0, src)) < TOL
