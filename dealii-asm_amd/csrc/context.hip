@@ -466,7 +466,7 @@ namespace
             prof_mark(ctx, 0, false);
             return ASM_OK;
           }
-        ctx->prof_used[0] -= 0; // begin event is simply re-recorded by the generic launch
+        // (the begin event is simply re-recorded by the generic launch below)
       }
     if (dst == ctx->exchanged_vec)
       ctx->exchanged_vec = nullptr;

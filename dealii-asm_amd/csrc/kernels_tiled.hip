@@ -1253,8 +1253,9 @@ namespace asmamd
               best      = nzc;
             }
         }
-      if (const char *e = std::getenv("ASM_TILED_ZCHUNKS")) // experiments only
-        best = std::max(1, std::min(std::atoi(e), g.nc[2]));
+      static const int forced = std::getenv("ASM_TILED_ZCHUNKS") ? std::atoi(std::getenv("ASM_TILED_ZCHUNKS")) : 0; // experiments only
+      if (forced > 0)
+        best = std::min(forced, g.nc[2]);
       tl.zlen = (g.nc[2] + best - 1) / best;
       tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
       return tl;
