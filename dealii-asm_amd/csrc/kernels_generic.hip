@@ -37,9 +37,89 @@ namespace asmamd
     };
 
     // out[a] = sum_i Q[i][a] in[i]   (forward, Q^T)
-    template <int M>
+    // a block-uniform eigenvector matrix in global memory: scalar loads, scalar operands of the FMAs
+    // (no LDS traffic for the matrix entries)
+    struct UniformMatrix
+    {
+      const __attribute__((address_space(4))) double *p;
+      __device__ __forceinline__ explicit UniformMatrix(const double *q)
+        : p((const __attribute__((address_space(4))) double *)q)
+      {}
+      __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
+    };
+    // even-odd forms for odd M and a matrix whose first (M+1)/2 columns are even and the others odd
+    // vectors (numerics.h: sort_eigenvectors_by_parity): about half the products
+    template <int M, typename QT>
     __device__ __forceinline__ void
-    sweep_fwd(const double *__restrict__ Q, double (&u)[M])
+    sweep_fwd_eo(const QT &Q, double (&u)[M])
+    {
+      constexpr int H = M / 2, NE = H + 1;
+      double        e[NE], o[H], t[M];
+#pragma unroll
+      for (int i = 0; i < H; ++i)
+        {
+          e[i] = u[i] + u[M - 1 - i];
+          o[i] = u[i] - u[M - 1 - i];
+        }
+      e[H] = u[H];
+#pragma unroll
+      for (int a = 0; a < NE; ++a)
+        {
+          double s = Q[0 * M + a] * e[0];
+#pragma unroll
+          for (int i = 1; i < NE; ++i)
+            s = fma(Q[i * M + a], e[i], s);
+          t[a] = s;
+        }
+#pragma unroll
+      for (int a = NE; a < M; ++a)
+        {
+          double s = Q[0 * M + a] * o[0];
+#pragma unroll
+          for (int i = 1; i < H; ++i)
+            s = fma(Q[i * M + a], o[i], s);
+          t[a] = s;
+        }
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+        u[a] = t[a];
+    }
+    template <int M, typename QT>
+    __device__ __forceinline__ void
+    sweep_bwd_eo(const QT &Q, double (&u)[M])
+    {
+      constexpr int H = M / 2, NE = H + 1;
+      double        E[NE], O[H];
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        {
+          double s = Q[i * M + 0] * u[0];
+#pragma unroll
+          for (int a = 1; a < NE; ++a)
+            s = fma(Q[i * M + a], u[a], s);
+          E[i] = s;
+        }
+#pragma unroll
+      for (int i = 0; i < H; ++i)
+        {
+          double s = Q[i * M + NE] * u[NE];
+#pragma unroll
+          for (int a = NE + 1; a < M; ++a)
+            s = fma(Q[i * M + a], u[a], s);
+          O[i] = s;
+        }
+#pragma unroll
+      for (int i = 0; i < H; ++i)
+        {
+          u[i]         = E[i] + O[i];
+          u[M - 1 - i] = E[i] - O[i];
+        }
+      u[H] = E[H];
+    }
+
+    template <int M, typename QT>
+    __device__ __forceinline__ void
+    sweep_fwd(const QT &Q, double (&u)[M])
     {
       double t[M];
 #pragma unroll
@@ -56,9 +136,9 @@ namespace asmamd
     }
 
     // out[i] = sum_a Q[i][a] in[a]   (backward, Q)
-    template <int M>
+    template <int M, typename QT>
     __device__ __forceinline__ void
-    sweep_bwd(const double *__restrict__ Q, double (&u)[M])
+    sweep_bwd(const QT &Q, double (&u)[M])
     {
       double t[M];
 #pragma unroll
@@ -73,6 +153,35 @@ namespace asmamd
 #pragma unroll
       for (int i = 0; i < M; ++i)
         u[i] = t[i];
+    }
+
+    template <int M, bool FWD>
+    __device__ __forceinline__ void
+    sweep_dir(const int mode, const double *__restrict__ Qlds, const UniformMatrix &U, double (&u)[M])
+    {
+      if constexpr ((M % 2) == 1)
+        if (mode == 2)
+          {
+            if (FWD)
+              sweep_fwd_eo<M>(U, u);
+            else
+              sweep_bwd_eo<M>(U, u);
+            return;
+          }
+      if (mode >= 1)
+        {
+          if (FWD)
+            sweep_fwd<M>(U, u);
+          else
+            sweep_bwd<M>(U, u);
+        }
+      else
+        {
+          if (FWD)
+            sweep_fwd<M>(Qlds, u);
+          else
+            sweep_bwd<M>(Qlds, u);
+        }
     }
 
     // STORE = false: contributions are added to dst with atomics (dst zeroed by the caller);
@@ -93,7 +202,7 @@ namespace asmamd
       const int  cell   = blockIdx.x * C::CPB + lc;
       const bool active = (lc < C::CPB) && (cell < ncells);
 
-      int c3[3] = {0, 0, 0};
+      int c3[3] = {0, 0, 0}, ids[3] = {0, 0, 0};
       if (active)
         {
           c3[0] = cell % g.nc[0];
@@ -106,11 +215,28 @@ namespace asmamd
             {
               const int     id = f.tensor_inst ? f.inst[d][c3[d] + 1] : f.inst[d][ce];
               const double *e  = f.eig + (long long)id * C::E;
+              ids[d]           = id;
               Qs[lc][d][lt]    = e[lt];
               if (lt < M)
                 Qs[lc][d][C::M2 + lt] = e[C::M2 + lt];
             }
         }
+      // Do all cells of the block share the instance of a direction (interior of a tensor-product mesh)?
+      // Then its matrix is read with scalar loads instead of 49 LDS reads per line.
+      int id0[3] = {0, 0, 0}, qmode[3] = {0, 0, 0};
+      {
+        const int cell0 = blockIdx.x * C::CPB; // first cell of the block: exists
+        const int c0[3] = {cell0 % g.nc[0], (cell0 / g.nc[0]) % g.nc[1], cell0 / (g.nc[0] * g.nc[1])};
+        const int ce0   = (c0[0] + 1) + (g.nc[0] + 2) * ((c0[1] + 1) + (g.nc[1] + 2) * (c0[2] + 1));
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          {
+            id0[d] = __builtin_amdgcn_readfirstlane(f.tensor_inst ? f.inst[d][c0[d] + 1] : f.inst[d][ce0]);
+            if (__syncthreads_and(!active || ids[d] == id0[d]))
+              qmode[d] = (f.eig_sym != nullptr && f.eig_sym[id0[d]] != 0) ? 2 : 1;
+          }
+      }
+      const UniformMatrix U0(f.eig + (long long)id0[0] * C::E), U1(f.eig + (long long)id0[1] * C::E), U2(f.eig + (long long)id0[2] * C::E);
 
       // thread (b, a) <-> lt = b*M + a
       const int a = lt % M, b = lt / M;
@@ -139,7 +265,7 @@ namespace asmamd
       __syncthreads(); // Qs visible
       if (active)
         {
-          sweep_fwd<M>(Qs[lc][2], u); // z forward
+          sweep_dir<M, true>(qmode[2], Qs[lc][2], U2, u); // z forward
 #pragma unroll
           for (int k = 0; k < M; ++k)
             T[lc][k * C::M2 + b * M + a] = u[k];
@@ -151,7 +277,7 @@ namespace asmamd
 #pragma unroll
           for (int j = 0; j < M; ++j)
             u[j] = T[lc][b * C::M2 + j * M + a];
-          sweep_fwd<M>(Qs[lc][1], u);
+          sweep_dir<M, true>(qmode[1], Qs[lc][1], U1, u);
 #pragma unroll
           for (int j = 0; j < M; ++j)
             T[lc][b * C::M2 + j * M + a] = u[j];
@@ -163,7 +289,7 @@ namespace asmamd
 #pragma unroll
           for (int i = 0; i < M; ++i)
             u[i] = T[lc][b * C::M2 + a * M + i];
-          sweep_fwd<M>(Qs[lc][0], u);
+          sweep_dir<M, true>(qmode[0], Qs[lc][0], U0, u);
           const double lyz = Qs[lc][1][C::M2 + a] + Qs[lc][2][C::M2 + b];
 #pragma unroll
           for (int i = 0; i < M; ++i)
@@ -175,7 +301,7 @@ namespace asmamd
               r               = fma(fma(-sm, r, 1.0), r, r);
               u[i] *= r;
             }
-          sweep_bwd<M>(Qs[lc][0], u);
+          sweep_dir<M, false>(qmode[0], Qs[lc][0], U0, u);
 #pragma unroll
           for (int i = 0; i < M; ++i)
             T[lc][b * C::M2 + a * M + i] = u[i];
@@ -187,7 +313,7 @@ namespace asmamd
 #pragma unroll
           for (int j = 0; j < M; ++j)
             u[j] = T[lc][b * C::M2 + j * M + a];
-          sweep_bwd<M>(Qs[lc][1], u);
+          sweep_dir<M, false>(qmode[1], Qs[lc][1], U1, u);
 #pragma unroll
           for (int j = 0; j < M; ++j)
             T[lc][b * C::M2 + j * M + a] = u[j];
@@ -199,7 +325,7 @@ namespace asmamd
 #pragma unroll
           for (int k = 0; k < M; ++k)
             u[k] = T[lc][k * C::M2 + b * M + a];
-          sweep_bwd<M>(Qs[lc][2], u);
+          sweep_dir<M, false>(qmode[2], Qs[lc][2], U2, u);
           const int    I = o0 + a, J = o1 + b;
           const bool   exy = g.exists(0, I) && g.exists(1, J);
           const double wxy = f.w_post[0][(c3[0] + 1) * M + a] * f.w_post[1][(c3[1] + 1) * M + b];
