@@ -422,9 +422,9 @@ namespace asmamd
     };
 
     // out[q] = sum_i A[q][i] in[i]
-    template <int N>
+    template <int N, typename AT>
     __device__ __forceinline__ void
-    apply_mat(const double *__restrict__ A, double (&u)[N])
+    apply_mat(const AT &A, double (&u)[N])
     {
       double t[N];
 #pragma unroll
@@ -441,9 +441,9 @@ namespace asmamd
         u[q] = t[q];
     }
     // out[i] = sum_q A[q][i] in[q]
-    template <int N>
+    template <int N, typename AT>
     __device__ __forceinline__ void
-    apply_mat_t(const double *__restrict__ A, double (&u)[N])
+    apply_mat_t(const AT &A, double (&u)[N])
     {
       double t[N];
 #pragma unroll
@@ -524,7 +524,9 @@ namespace asmamd
       constexpr int N1 = C::N1, N2 = C::N2, N3 = C::N3;
       __shared__ double T0[C::CPB][N3], T1[C::CPB][N3], T2[C::CPB][N3];
       __shared__ double Gs[C::CPB][81];
-      __shared__ double Ns[N2], Ds[N2], xqs[N1], wqs[N1];
+      __shared__ double Ds[N2], xqs[N1], wqs[N1];
+      // the interpolation matrix is the same for every cell: scalar operands instead of LDS reads
+      const UniformMatrix Nu(op.N);
 
       const int  tid    = threadIdx.x;
       const int  lc     = tid / N2;
@@ -534,7 +536,6 @@ namespace asmamd
       const bool active = (lc < C::CPB) && (cell < ncells);
       if (tid < N2)
         {
-          Ns[tid] = op.N[tid];
           Ds[tid] = op.Dc[tid];
         }
       if (tid < N1)
@@ -592,7 +593,7 @@ namespace asmamd
           // interpolate to quadrature points: z (registers), y, x
           if (active)
             {
-              apply_mat<N1>(Ns, u);
+              apply_mat<N1>(Nu, u);
 #pragma unroll
               for (int k = 0; k < N1; ++k)
                 T0[lc][k * N2 + b * N1 + a] = u[k];
@@ -603,7 +604,7 @@ namespace asmamd
 #pragma unroll
               for (int j = 0; j < N1; ++j)
                 u[j] = T0[lc][b * N2 + j * N1 + a];
-              apply_mat<N1>(Ns, u);
+              apply_mat<N1>(Nu, u);
 #pragma unroll
               for (int j = 0; j < N1; ++j)
                 T0[lc][b * N2 + j * N1 + a] = u[j];
@@ -614,7 +615,7 @@ namespace asmamd
 #pragma unroll
               for (int i = 0; i < N1; ++i)
                 u[i] = T0[lc][b * N2 + a * N1 + i];
-              apply_mat<N1>(Ns, u);
+              apply_mat<N1>(Nu, u);
 #pragma unroll
               for (int i = 0; i < N1; ++i)
                 T0[lc][b * N2 + a * N1 + i] = u[i];
@@ -690,7 +691,7 @@ namespace asmamd
                     }
                   u[qz] = s;
                 }
-              apply_mat_t<N1>(Ns, u); // z
+              apply_mat_t<N1>(Nu, u); // z
             }
           __syncthreads(); // all reads of T0 (vz, rows) are done
           if (active)
@@ -705,7 +706,7 @@ namespace asmamd
 #pragma unroll
               for (int j = 0; j < N1; ++j)
                 u[j] = T0[lc][b * N2 + j * N1 + a];
-              apply_mat_t<N1>(Ns, u);
+              apply_mat_t<N1>(Nu, u);
 #pragma unroll
               for (int j = 0; j < N1; ++j)
                 T0[lc][b * N2 + j * N1 + a] = u[j];
@@ -716,7 +717,7 @@ namespace asmamd
 #pragma unroll
               for (int i = 0; i < N1; ++i)
                 u[i] = T0[lc][b * N2 + a * N1 + i];
-              apply_mat_t<N1>(Ns, u);
+              apply_mat_t<N1>(Nu, u);
 #pragma unroll
               for (int i = 0; i < N1; ++i)
                 T0[lc][b * N2 + a * N1 + i] = u[i];
