@@ -48,6 +48,8 @@ namespace asmamd
         throw std::runtime_error(std::string("dealii_asm_amd: ") + asm_last_error(handle_.get()));
     }
     void synchronize() const { check(asm_synchronize(handle_.get())); }
+    // promise that vectors are modified between calls only through this library (asm_set_keep_ghosts)
+    void set_keep_ghosts(const bool on) const { check(asm_set_keep_ghosts(handle_.get(), on ? 1 : 0)); }
 
   private:
     std::shared_ptr<asm_ctx> handle_;
