@@ -65,6 +65,8 @@ struct asm_ctx
   HostSetup                s;
   std::unique_ptr<Basis1D> basis;
   hipStream_t              stream = nullptr;
+  int                      device = 0; // HIP device ordinal every call of this context runs on
+  int                      n_cu   = 0; // its compute units (tile scheduling of the tiled sweeps)
   DevGrid                  g;
   DevFdm                   f;
   DevOp                    op;
@@ -144,6 +146,36 @@ struct asm_ctx
 
 namespace
 {
+  // Every entry point runs on the context's device, whatever the calling thread's current device is,
+  // and leaves the thread's current device as it found it.
+  struct DeviceScope
+  {
+    int  prev = -1;
+    bool switched = false;
+    explicit DeviceScope(const asm_ctx *ctx)
+    {
+      if (ctx != nullptr && hipGetDevice(&prev) == hipSuccess && prev != ctx->device)
+        switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+      if (switched)
+        (void)hipSetDevice(prev);
+    }
+  };
+
+  // A rejected launch (LDS limit, bad grid, other architecture) must not leave the call looking
+  // successful: fetch the runtime's sticky launch error after the launches of an operation.
+  int
+  launch_status(asm_ctx *ctx, const char *where)
+  {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+      return ASM_OK;
+    ctx->error = std::string("kernel launch failed in ") + where + ": " + hipGetErrorString(e);
+    return ASM_ERR_DEVICE;
+  }
+
   template <typename T>
   int
   upload(asm_ctx *ctx, const std::vector<T> &h, const T **d)
@@ -226,6 +258,8 @@ namespace
       }
     if (!add && ctx->exchanged_vec == v)
       return ASM_OK; // filled by the overlapped exchange that followed the sweep which produced v
+    if (add && ctx->exchanged_vec == v)
+      ctx->exchanged_vec = nullptr; // compress(add) changes owned values and zeroes the ghost planes
     const DevGrid &g = ctx->g;
     if (ctx->loop)
       {
@@ -417,6 +451,8 @@ namespace
     for (int d = 0; d < 3; ++d)
       for (int f = 0; f < 2; ++f)
         a.iface[d][f] = ctx->s.face[d][f] == FACE_INTERFACE;
+    a.device = ctx->device;
+    a.n_cu   = ctx->n_cu;
     if (!ov && ctx->debug_two_phase)
       {
         a.phase = 1;
@@ -446,7 +482,7 @@ namespace
   // dst = A src (OP_PLAIN) or dst = b - A src with identity rows on constrained
   // DoFs (OP_RESIDUAL); src's ghosts are updated here.
   int
-  op_apply(asm_ctx *ctx, const int mode, double *dst, double *src, const double *b)
+  op_apply_impl(asm_ctx *ctx, const int mode, double *dst, double *src, const double *b)
   {
     int err = exchange(ctx, src, false);
     if (err)
@@ -490,10 +526,17 @@ namespace
     return ASM_OK;
   }
 
+  int
+  op_apply(asm_ctx *ctx, const int mode, double *dst, double *src, const double *b)
+  {
+    const int err = op_apply_impl(ctx, mode, dst, src, b);
+    return err ? err : launch_status(ctx, "the Laplace sweep");
+  }
+
   // dst = [f(x, x_old) +] f2 * P^-1 src, see TiledMode
   int
-  pc_apply(asm_ctx *ctx, const int mode, double *dst, double *src, const double *x, const double *x_old, const double f1,
-           const double f2)
+  pc_apply_impl(asm_ctx *ctx, const int mode, double *dst, double *src, const double *x, const double *x_old, const double f1,
+                const double f2)
   {
     const long long n = ctx->s.n_alloc;
     if (ctx->s.prm.precond_type == ASM_PRECOND_DIAGONAL)
@@ -561,6 +604,14 @@ namespace
     else if (mode == PC_UPDATE)
       vec_cheb_update(dst, x, x_old, t, f1, f2, n, ctx->stream);
     return ASM_OK;
+  }
+
+  int
+  pc_apply(asm_ctx *ctx, const int mode, double *dst, double *src, const double *x, const double *x_old, const double f1,
+           const double f2)
+  {
+    const int err = pc_apply_impl(ctx, mode, dst, src, x, x_old, f1, f2);
+    return err ? err : launch_status(ctx, "the preconditioner sweep");
   }
 
   // PreconditionChebyshev::vmult / step [deal.II], first-kind polynomial:
@@ -771,6 +822,9 @@ asm_create(const asm_params *p, asm_ctx **out)
     g_create_error = ctx->error;
     for (void *q : ctx->allocs)
       (void)hipFree(q);
+    if (ctx->h_scalar)
+      (void)hipHostFree(ctx->h_scalar);
+    (void)hipGetLastError();
     return code;
   };
   if (!setup_layout(*p, ctx->s))
@@ -784,11 +838,23 @@ asm_create(const asm_params *p, asm_ctx **out)
       ctx->error = "no HIP device available (the MI355X path has no CPU fallback)";
       return fail(ASM_ERR_NO_DEVICE);
     }
-  if (p->device >= 0 && hipSetDevice(p->device) != hipSuccess)
+  if (p->device >= n_dev || (p->device < 0 && hipGetDevice(&ctx->device) != hipSuccess))
     {
-      ctx->error = "hipSetDevice failed";
+      ctx->error = "invalid HIP device ordinal";
       return fail(ASM_ERR_DEVICE);
     }
+  if (p->device >= 0)
+    ctx->device = p->device;
+  const DeviceScope device_scope(ctx);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess)
+      {
+        ctx->error = "hipGetDeviceProperties failed";
+        return fail(ASM_ERR_DEVICE);
+      }
+    ctx->n_cu = prop.multiProcessorCount;
+  }
   ctx->stream = (hipStream_t)p->stream;
   try
     {
@@ -968,6 +1034,7 @@ asm_destroy(asm_ctx *ctx)
 {
   if (!ctx)
     return;
+  const DeviceScope device_scope(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm_stream)
     {
@@ -1041,6 +1108,7 @@ asm_debug_loopback_init(asm_ctx **ctxs, int n)
 int
 asm_comm_init(asm_ctx *ctx, const char id[128])
 {
+  const DeviceScope device_scope(ctx);
   ncclUniqueId uid;
   std::memcpy(&uid, id, 128);
   NCCL_TRY(ncclCommInitRank(&ctx->comm, ctx->s.prm.world_size, uid, ctx->s.prm.rank));
@@ -1062,12 +1130,14 @@ asm_vector_layout(const asm_ctx *ctx, asm_layout *out)
 int
 asm_vector_alloc(asm_ctx *ctx, double **v)
 {
+  const DeviceScope device_scope(ctx);
   return alloc_vec(ctx, v);
 }
 
 int
 asm_vector_free(asm_ctx *ctx, double *v)
 {
+  const DeviceScope device_scope(ctx);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->comm_stream)
     HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
@@ -1080,6 +1150,7 @@ asm_vector_free(asm_ctx *ctx, double *v)
 int
 asm_vector_import(asm_ctx *ctx, double *dev, const double *host_owned)
 {
+  const DeviceScope device_scope(ctx);
   const DevGrid &g = ctx->g;
   const int      lo[3] = {0, 0, 0}, size[3] = {g.own_hi[0] + 1, g.own_hi[1] + 1, g.own_hi[2] + 1};
   double *       buf   = nullptr;
@@ -1100,6 +1171,7 @@ asm_vector_import(asm_ctx *ctx, double *dev, const double *host_owned)
 int
 asm_vector_export(asm_ctx *ctx, double *host_owned, const double *dev)
 {
+  const DeviceScope device_scope(ctx);
   const DevGrid &g = ctx->g;
   const int      lo[3] = {0, 0, 0}, size[3] = {g.own_hi[0] + 1, g.own_hi[1] + 1, g.own_hi[2] + 1};
   double *       buf   = nullptr;
@@ -1114,18 +1186,21 @@ asm_vector_export(asm_ctx *ctx, double *host_owned, const double *dev)
 int
 asm_update_ghost_values(asm_ctx *ctx, double *v)
 {
+  const DeviceScope device_scope(ctx);
   return exchange(ctx, v, false);
 }
 
 int
 asm_compress_add(asm_ctx *ctx, double *v)
 {
+  const DeviceScope device_scope(ctx);
   return exchange(ctx, v, true);
 }
 
 int
 asm_op_vmult(asm_ctx *ctx, double *dst, const double *src)
 {
+  const DeviceScope device_scope(ctx);
   if (!ctx->keep_ghosts)
     ctx->exchanged_vec = nullptr;
   return op_apply(ctx, OP_PLAIN, dst, const_cast<double *>(src), nullptr);
@@ -1134,6 +1209,9 @@ asm_op_vmult(asm_ctx *ctx, double *dst, const double *src)
 int
 asm_op_inverse_diagonal(asm_ctx *ctx, double *out)
 {
+  const DeviceScope device_scope(ctx);
+  if (out == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
   HIP_TRY(hipMemsetAsync(out, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
   if (!laplace_generic(ctx->g, ctx->op, nullptr, out, true, ctx->stream))
     {
@@ -1144,12 +1222,13 @@ asm_op_inverse_diagonal(asm_ctx *ctx, double *out)
   if (err)
     return err;
   vec_invert_diagonal(out, ctx->s.n_alloc, ctx->stream);
-  return ASM_OK;
+  return launch_status(ctx, "compute_inverse_diagonal");
 }
 
 int
 asm_precond_vmult(asm_ctx *ctx, double *dst, const double *src)
 {
+  const DeviceScope device_scope(ctx);
   if (!ctx->keep_ghosts)
     ctx->exchanged_vec = nullptr;
   return pc_apply(ctx, PC_PLAIN, dst, const_cast<double *>(src), nullptr, nullptr, 0., 1.);
@@ -1176,6 +1255,7 @@ asm_cheb_set_eigenvalue(asm_ctx *ctx, double lambda_max)
 int
 asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max)
 {
+  const DeviceScope device_scope(ctx);
   const asm_params &prm = ctx->s.prm;
   const long long   n   = ctx->s.n_alloc;
   int               alg = prm.ev_algorithm;
@@ -1188,8 +1268,6 @@ asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max)
       alg = symmetric ? ASM_EV_LANCZOS : ASM_EV_POWER_ITERATION;
     }
   double *v = nullptr, *w = nullptr, *z = nullptr, *q = nullptr;
-  if (alloc_vec(ctx, &v) || alloc_vec(ctx, &w) || alloc_vec(ctx, &z) || alloc_vec(ctx, &q))
-    return ASM_ERR_DEVICE;
   const auto cleanup = [&](const int code) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(v);
@@ -1198,6 +1276,8 @@ asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max)
     (void)hipFree(q);
     return code;
   };
+  if (alloc_vec(ctx, &v) || alloc_vec(ctx, &w) || alloc_vec(ctx, &z) || alloc_vec(ctx, &q))
+    return cleanup(ASM_ERR_DEVICE);
   // set_initial_guess [deal.II]: (global index % 11) - mean, constrained entries zeroed
   long long gbegin[3], gsize[3];
   for (int d = 0; d < 3; ++d)
@@ -1241,7 +1321,11 @@ asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max)
       double              rz, r0, tmp;
       if ((err = pc_apply(ctx, PC_PLAIN, z, r, nullptr, nullptr, 0., 1.)))
         return cleanup(err);
-      HIP_TRY(hipMemcpyAsync(pv, z, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      if (hipMemcpyAsync(pv, z, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+        {
+          ctx->error = "hipMemcpyAsync failed in the eigenvalue estimate";
+          return cleanup(ASM_ERR_DEVICE);
+        }
       if ((err = dot(ctx, r, z, &rz)) || (err = dot(ctx, r, r, &r0)))
         return cleanup(err);
       r0 = std::sqrt(r0);
@@ -1285,12 +1369,14 @@ asm_cheb_estimate_eigenvalues(asm_ctx *ctx, double *lambda_max)
 int
 asm_cheb_vmult(asm_ctx *ctx, double *dst, const double *src)
 {
+  const DeviceScope device_scope(ctx);
   return cheb_run(ctx, dst, src, true);
 }
 
 int
 asm_cheb_step(asm_ctx *ctx, double *dst, const double *src)
 {
+  const DeviceScope device_scope(ctx);
   return cheb_run(ctx, dst, src, false);
 }
 
@@ -1327,6 +1413,7 @@ asm_kernel_variant_in_use(const asm_ctx *ctx, int32_t *variant)
 int
 asm_synchronize(asm_ctx *ctx)
 {
+  const DeviceScope device_scope(ctx);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->comm_stream)
     HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
@@ -1353,6 +1440,7 @@ asm_profile_enable(asm_ctx *ctx, int on)
 int
 asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms)
 {
+  const DeviceScope device_scope(ctx);
   if (kernel < 0 || kernel > 1)
     {
       ctx->error = "asm_profile_get: kernel must be 0 (Laplace sweep) or 1 (FDM sweep)";
@@ -1491,6 +1579,7 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
 int
 asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms)
 {
+  const DeviceScope device_scope(ctx);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));

@@ -41,6 +41,9 @@ namespace asmamd
     // 2 = the others
     int phase       = 0;
     int iface[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    // host side only: the device the launch goes to and its number of compute units (no process-global caches)
+    int device = 0;
+    int n_cu   = 0;
   };
   bool laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st);
   bool fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st);

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace asmamd
@@ -1218,7 +1219,7 @@ namespace asmamd
     }
 
     Tiling
-    make_tiling(const DevGrid &g)
+    make_tiling(const DevGrid &g, int n_cu)
     {
       Tiling tl;
       tl.ntx = (g.nc[0] + OX - 1) / OX;
@@ -1229,16 +1230,8 @@ namespace asmamd
       // One workgroup per CU at a time.  Workgroups run in rounds of n_cu; a chunk of zlen layers
       // costs zlen + 1 layer times (halo layer) plus about half a layer of start-up: take the
       // number of chunks with the smallest  rounds x (zlen + 1.5).
-      static int n_cu = 0;
-      if (n_cu == 0)
-        {
-          int dev = 0;
-          hipDeviceProp_t prop;
-          if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n_cu = prop.multiProcessorCount;
-          if (n_cu <= 0)
-            n_cu = 256;
-        }
+      if (n_cu <= 0)
+        n_cu = 256;
       int    best      = 1;
       double best_cost = 1e300;
       for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
@@ -1261,27 +1254,36 @@ namespace asmamd
       return tl;
     }
 
+    // The kernels need more dynamic LDS than the default limit: raise it once per kernel and device
+    // (bit d of `done` = device d).  false: the attribute was refused, the launch would be rejected.
     template <typename K>
-    void
-    set_lds_limit(K kernel)
+    bool
+    set_lds_limit(K kernel, std::atomic<unsigned long long> &done, const int device)
     {
-      (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(LDS_TOTAL * sizeof(double)));
+      const unsigned long long bit = 1ull << (device & 63);
+      if (done.load(std::memory_order_acquire) & bit)
+        return true;
+      if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(LDS_TOTAL * sizeof(double))) != hipSuccess)
+        {
+          (void)hipGetLastError();
+          return false;
+        }
+      done.fetch_or(bit, std::memory_order_release);
+      return true;
     }
   } // namespace
 
   template <int MODE>
-  static void
+  static bool
   launch_laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, const Tiling &tl, hipStream_t st)
   {
-    static bool done = false;
-    if (!done)
-      {
-        set_lds_limit(laplace_cart_tiled_kernel<MODE>);
-        done = true;
-      }
+    static std::atomic<unsigned long long> done{0};
+    if (!set_lds_limit(laplace_cart_tiled_kernel<MODE>, done, a.device))
+      return false;
     hipLaunchKernelGGL((laplace_cart_tiled_kernel<MODE>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(NT), LDS_TOTAL * sizeof(double),
                        st, g, op, a, tl);
+    return true;
   }
 
   bool
@@ -1289,38 +1291,33 @@ namespace asmamd
   {
     if (g.p != P || !op.cartesian)
       return false;
-    const Tiling tl = make_tiling(g);
+    const Tiling tl = make_tiling(g, a.n_cu);
     if (a.mode == OP_PLAIN)
-      launch_laplace_tiled<OP_PLAIN>(g, op, a, tl, st);
-    else if (a.mode == OP_RESIDUAL)
-      launch_laplace_tiled<OP_RESIDUAL>(g, op, a, tl, st);
-    else
-      return false;
-    return true;
+      return launch_laplace_tiled<OP_PLAIN>(g, op, a, tl, st);
+    if (a.mode == OP_RESIDUAL)
+      return launch_laplace_tiled<OP_RESIDUAL>(g, op, a, tl, st);
+    return false;
   }
 
   template <int MODE, bool HAS_PRE, bool HAS_POST, bool TENSOR>
-  static void
+  static bool
   launch_fdm_tiled_t(const DevGrid &g, const DevFdm &f, const TiledArgs &a, const Tiling &tl, hipStream_t st)
   {
-    static bool done = false;
-    if (!done)
-      {
-        set_lds_limit(fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>);
-        done = true;
-      }
+    static std::atomic<unsigned long long> done{0};
+    if (!set_lds_limit(fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>, done, a.device))
+      return false;
     hipLaunchKernelGGL((fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(NT),
                        LDS_TOTAL * sizeof(double), st, g, f, a, tl);
+    return true;
   }
 
   template <int MODE, bool HAS_PRE, bool HAS_POST>
-  static void
+  static bool
   launch_fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, const Tiling &tl, hipStream_t st)
   {
     if (f.tensor_inst && f.n_inst <= 16)
-      launch_fdm_tiled_t<MODE, HAS_PRE, HAS_POST, true>(g, f, a, tl, st);
-    else
-      launch_fdm_tiled_t<MODE, HAS_PRE, HAS_POST, false>(g, f, a, tl, st);
+      return launch_fdm_tiled_t<MODE, HAS_PRE, HAS_POST, true>(g, f, a, tl, st);
+    return launch_fdm_tiled_t<MODE, HAS_PRE, HAS_POST, false>(g, f, a, tl, st);
   }
 
   template <bool HAS_PRE, bool HAS_POST>
@@ -1329,10 +1326,10 @@ namespace asmamd
   {
     switch (a.mode)
       {
-        case PC_PLAIN: launch_fdm_tiled<PC_PLAIN, HAS_PRE, HAS_POST>(g, f, a, tl, st); return true;
-        case PC_FIRST: launch_fdm_tiled<PC_FIRST, HAS_PRE, HAS_POST>(g, f, a, tl, st); return true;
-        case PC_STEP1: launch_fdm_tiled<PC_STEP1, HAS_PRE, HAS_POST>(g, f, a, tl, st); return true;
-        case PC_UPDATE: launch_fdm_tiled<PC_UPDATE, HAS_PRE, HAS_POST>(g, f, a, tl, st); return true;
+        case PC_PLAIN: return launch_fdm_tiled<PC_PLAIN, HAS_PRE, HAS_POST>(g, f, a, tl, st);
+        case PC_FIRST: return launch_fdm_tiled<PC_FIRST, HAS_PRE, HAS_POST>(g, f, a, tl, st);
+        case PC_STEP1: return launch_fdm_tiled<PC_STEP1, HAS_PRE, HAS_POST>(g, f, a, tl, st);
+        case PC_UPDATE: return launch_fdm_tiled<PC_UPDATE, HAS_PRE, HAS_POST>(g, f, a, tl, st);
         default: return false;
       }
   }
@@ -1342,7 +1339,7 @@ namespace asmamd
   {
     if (g.p != P || f.m != N1 || f.vertex)
       return false;
-    const Tiling tl = make_tiling(g);
+    const Tiling tl = make_tiling(g, a.n_cu);
     if (f.has_pre && f.has_post)
       return dispatch_fdm_mode<true, true>(g, f, a, tl, st);
     if (f.has_pre)

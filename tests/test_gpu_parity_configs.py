@@ -1,0 +1,168 @@
+"""GPU parity of the BASELINE.json configurations that need the 7^3 / 10^3 patch kernels and the
+deformed-cell operator, against the numpy oracle (same tolerance as test_gpu_parity.py):
+
+  config 3  Kershaw, p=4, n_overlap=2 (m=7), post weights, Chebyshev k=2   (experiments/large-scaling-opt_fdm2.json:13-25)
+  config 4  p=4, vertex-star patches (m=7), symm weights, Chebyshev k=2    (experiments/large-scaling-opt_fdmv.json:13-25)
+  config 5  Kershaw, p=7, RAS, n_overlap=2 (m=10), Chebyshev k=3           (experiments/large-scaling-opt_ras.json:13-25)
+
+and the bench workload at full size (80^3 cells) against the threaded C++ restatement.
+Mesh sizes are chosen so that the generic FDM kernel meets all its matrix paths: blocks of cells
+that share a parity-sorted instance (even-odd sweeps), share a boundary instance (scalar operands),
+or mix instances (LDS matrices)."""
+import os
+
+import numpy as np
+import pytest
+
+import asm_oracle as orc
+from test_gpu_parity import TOL, make_pair, rel
+
+pytestmark = pytest.mark.gpu
+
+# (nc, bc, geometry, n_overlap, element_centric)
+M7_CASES = [
+    ((5, 4, 3), "dirichlet", "cartesian", 2, True),
+    ((4, 3, 3), "periodic", "cartesian", 2, True),
+    ((5, 3, 3), ["periodic", "dirichlet", "neumann"], "cartesian", 2, True),
+    ((6, 2, 2), "dirichlet", "kershaw", 2, True),
+    ((5, 4, 3), "dirichlet", "cartesian", 1, False),
+    ((4, 3, 3), "periodic", "cartesian", 1, False),
+    ((6, 3, 2), "dirichlet", "kershaw", 1, False),
+]
+
+
+@pytest.fixture(params=[False, True], ids=["store_gather", "atomics"])
+def fdm_atomics(request):
+    """the generic FDM sweep has two scatter forms (context.hip: patch_tmp / ASM_FDM_ATOMICS)"""
+    old = os.environ.get("ASM_FDM_ATOMICS")
+    if request.param:
+        os.environ["ASM_FDM_ATOMICS"] = "1"
+    else:
+        os.environ.pop("ASM_FDM_ATOMICS", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("ASM_FDM_ATOMICS", None)
+    else:
+        os.environ["ASM_FDM_ATOMICS"] = old
+
+
+@pytest.mark.parametrize("weighting", ["none", "pre", "post", "symm", "ras"])
+@pytest.mark.parametrize("nc,bc,geometry,n_overlap,element_centric", M7_CASES)
+def test_precond_vmult_p4_m7(pkg, fdm_atomics, nc, bc, geometry, n_overlap, element_centric, weighting):
+    mesh, ctx = make_pair(pkg, nc, 4, bc, geometry, eps=(0.3, 0.3), n_overlap=n_overlap, weighting=weighting,
+                          element_centric=element_centric)
+    with ctx:
+        src = np.random.default_rng(7).uniform(-1, 1, mesh.n_dofs)
+        ref = orc.ASPoissonPreconditioner(mesh, n_overlap, weighting, element_centric).vmult(src)
+        x, y = ctx.vector(src), ctx.vector(np.full(mesh.n_dofs, 123.0))
+        ctx.precond_vmult(y, x)
+        assert rel(y.get(), ref) < TOL
+
+
+@pytest.mark.parametrize(
+    "nc,bc,geometry,n_overlap,element_centric,weighting",
+    [
+        ((6, 2, 2), "dirichlet", "kershaw", 2, True, "post"),  # config 3 (file variant)
+        ((5, 4, 3), "dirichlet", "cartesian", 2, True, "post"),
+        ((4, 3, 3), "periodic", "cartesian", 1, False, "symm"),  # config 4
+        ((6, 3, 2), "dirichlet", "kershaw", 1, False, "symm"),  # the file behind config 4 is a Kershaw mesh
+        ((6, 2, 2), "dirichlet", "kershaw", 2, True, "ras"),
+    ],
+)
+@pytest.mark.parametrize("degree", [1, 2, 3])
+def test_chebyshev_p4_m7(pkg, nc, bc, geometry, n_overlap, element_centric, weighting, degree):
+    mesh, ctx = make_pair(pkg, nc, 4, bc, geometry, eps=(0.3, 0.3), n_overlap=n_overlap, weighting=weighting,
+                          element_centric=element_centric, cheb_degree=degree)
+    with ctx:
+        op = orc.LaplaceOperator(mesh)
+        prec = orc.ASPoissonPreconditioner(mesh, n_overlap, weighting, element_centric)
+        cheb = orc.Chebyshev(op, prec, degree=degree, lambda_max=1.7)
+        ctx.set_eigenvalue(1.7)
+        rng = np.random.default_rng(11)
+        b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+        bv, xv = ctx.vector(b), ctx.vector()
+        ctx.cheb_vmult(xv, bv)
+        assert rel(xv.get(), cheb.vmult(b)) < TOL
+        xv.set(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), cheb.step(x0, b)) < TOL
+
+
+@pytest.mark.parametrize("nc,bc,geometry", [((3, 2, 2), "dirichlet", "kershaw"), ((2, 3, 2), ["dirichlet", "neumann", "dirichlet"], "kershaw"),
+                                            ((4, 4, 4), "dirichlet", "kershaw")])
+def test_op_vmult_p7_deformed(pkg, nc, bc, geometry):
+    mesh, ctx = make_pair(pkg, nc, 7, bc, geometry, eps=(0.3, 0.3))
+    with ctx:
+        src = np.random.default_rng(2024).uniform(-1, 1, mesh.n_dofs)
+        ref = orc.LaplaceOperator(mesh).vmult(src)
+        x, y = ctx.vector(src), ctx.vector()
+        ctx.op_vmult(y, x)
+        assert rel(y.get(), ref) < TOL
+
+
+@pytest.mark.parametrize("weighting", ["ras", "post", "symm"])
+@pytest.mark.parametrize("nc,bc,geometry", [((3, 2, 2), "dirichlet", "kershaw"), ((3, 3, 2), "dirichlet", "cartesian"),
+                                            ((2, 2, 2), "periodic", "cartesian")])
+def test_precond_vmult_p7_m10(pkg, fdm_atomics, nc, bc, geometry, weighting):
+    """config 5: p=7, n_overlap=2 -> 10^3 patches"""
+    mesh, ctx = make_pair(pkg, nc, 7, bc, geometry, eps=(0.3, 0.3), n_overlap=2, weighting=weighting)
+    with ctx:
+        src = np.random.default_rng(7).uniform(-1, 1, mesh.n_dofs)
+        ref = orc.ASPoissonPreconditioner(mesh, 2, weighting).vmult(src)
+        x, y = ctx.vector(src), ctx.vector(np.full(mesh.n_dofs, 123.0))
+        ctx.precond_vmult(y, x)
+        assert rel(y.get(), ref) < TOL
+
+
+def test_precond_vmult_p7_vertex_star_m13(pkg):
+    mesh, ctx = make_pair(pkg, (3, 2, 2), 7, "dirichlet", "kershaw", eps=(0.3, 0.3), weighting="symm", element_centric=False)
+    with ctx:
+        src = np.random.default_rng(7).uniform(-1, 1, mesh.n_dofs)
+        ref = orc.ASPoissonPreconditioner(mesh, 1, "symm", False).vmult(src)
+        x, y = ctx.vector(src), ctx.vector()
+        ctx.precond_vmult(y, x)
+        assert rel(y.get(), ref) < TOL
+
+
+def test_chebyshev_p7_ras_config5(pkg):
+    nc = (3, 2, 2)
+    mesh, ctx = make_pair(pkg, nc, 7, "dirichlet", "kershaw", eps=(0.3, 0.3), n_overlap=2, weighting="ras", cheb_degree=3)
+    with ctx:
+        op = orc.LaplaceOperator(mesh)
+        prec = orc.ASPoissonPreconditioner(mesh, 2, "ras")
+        cheb = orc.Chebyshev(op, prec, degree=3, lambda_max=1.5)
+        ctx.set_eigenvalue(1.5)
+        rng = np.random.default_rng(11)
+        b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+        bv, xv = ctx.vector(b), ctx.vector()
+        ctx.cheb_vmult(xv, bv)
+        assert rel(xv.get(), cheb.vmult(b)) < TOL
+        xv.set(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), cheb.step(x0, b)) < TOL
+
+
+# ---------------------------------------------------------------------------
+# the bench workload at full size against the threaded C++ restatement (itself checked against the
+# numpy oracle in tests/test_oracle_cpu_port.py)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nc,periodic,degree", [((80, 80, 80), False, 1), ((80, 80, 80), False, 3), ((64, 32, 32), True, 2)])
+def test_full_size_bench_workload(pkg, nc, periodic, degree):
+    import subprocess
+
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")],
+                   check=True, capture_output=True)
+    import asm_oracle_cpu
+
+    lam = 1.7
+    sm = asm_oracle_cpu.CpuSmoother(nc, periodic, degree=degree, lambda_max=lam, n_threads=min(16, os.cpu_count() or 1))
+    rng = np.random.default_rng(5)
+    b, x0 = rng.uniform(-1, 1, sm.n_dofs), rng.uniform(-1, 1, sm.n_dofs)
+    ref = sm.step(x0, b)
+    with pkg.Context(degree=4, n_cells=nc, boundary="periodic" if periodic else "dirichlet", cheb_degree=degree,
+                     kernel="tiled") as ctx:
+        assert ctx.n_dofs == sm.n_dofs and ctx.kernel_variant() == "tiled"
+        ctx.set_eigenvalue(lam)
+        bv, xv = ctx.vector(b), ctx.vector(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), ref) < TOL

@@ -134,3 +134,26 @@ def test_chebyshev_vmult_is_step_from_zero():
     r0[op.constrained] = 0
     r1 = b - op.vmult(x, unit_constrained=True)
     assert np.linalg.norm(r1) < np.linalg.norm(r0)
+
+
+def test_patch_index_sets_match_reference_fixture():
+    """indices_overlap_01.output: the DoF index list (deal.II numbering, lexicographic patch order, missing
+    neighbours skipped) of every element-centred patch of an 8x8 mesh, FE_Q(2), n_overlap = 0..3
+    (DoFTools::get_dof_indices_cell_with_overlap, include/dof_tools.h:10-137).  Pins the box shape
+    m = p + 2 n - 1, its origin p c - (n - 1) and the x-fastest ordering that oracle and HIP path share."""
+    from dealii_numbering import morton_cells
+
+    gold = json.load(open(os.path.join(HERE, "golden", "indices_overlap_01.json")))
+    p, level = gold["degree"], gold["level"]
+    nc = 2**level
+    mesh = orc.Mesh((nc, nc), p, [orc.NEUMANN, orc.NEUMANN])  # no constraints in the fixture
+    num = dealii_numbering_2d(level, p)
+    order = morton_cells(level)  # deal.II's active-cell order of a globally refined hyper_cube
+    assert len(order) == len(gold["cells"])
+    for (cx, cy), lists in zip(order, gold["cells"]):
+        c = cx + nc * cy
+        for n_overlap, expect in enumerate(lists):
+            m = p + 2 * n_overlap - 1
+            idx, valid = mesh.box_indices([p * cc - (n_overlap - 1) for cc in mesh.cc], m)
+            got = num[idx[c][valid[c]]]
+            assert list(got) == expect, (cx, cy, n_overlap)
