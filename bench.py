@@ -47,7 +47,7 @@ def algorithmic_bytes_per_dof(degree, what):
     return a_sweeps, p_sweeps
 
 
-def cpu_baseline(args, pkg):
+def cpu_baseline(args, pkg, cells):
     """The same smoother application on the host cores, on a bounded sample of the workload.
     Cartesian workloads: the threaded C++ restatement oracle/asm_oracle_cpu.cc (kind "port",
     checked against the numpy oracle in tests/test_oracle_cpu_port.py), all host threads.
@@ -55,28 +55,38 @@ def cpu_baseline(args, pkg):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import asm_oracle as orc
 
+    # host cores this process may use (the GPU box gives one GPU's CPU share) vs what the node has
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
     if args.workload != "kershaw":
         import asm_oracle_cpu
 
-        threads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
-        nc = (40, 40, 40) if args.workload == "cart_dirichlet" else (48, 32, 32)
+        threads = max(1, usable if args.cpu_threads <= 0 else min(usable, args.cpu_threads))
+        nc = tuple(cells)  # the mesh of the GPU measurement itself
         sm = asm_oracle_cpu.CpuSmoother(nc, args.workload == "cart_periodic", degree=args.degree, lambda_max=1.7, n_threads=threads)
         b = np.ones(sm.n_dofs)
-        x = sm.step(np.zeros(sm.n_dofs), b)  # warm-up
+        # each call sets up its thread pool and first-touches its work vectors: several steps per call
+        x = sm.step(np.zeros(sm.n_dofs), b, reps=2)  # warm-up
+        per_call = 8
         reps, t0 = 0, time.perf_counter()
         while True:
-            x = sm.step(x, b, reps=2)
-            reps += 2
+            x = sm.step(x, b, reps=per_call)
+            reps += per_call
             el = time.perf_counter() - t0
-            if el > 10.0 or reps >= 400:
+            if el > 12.0 or reps >= 400:
                 break
         return {
             "value": sm.n_dofs * reps / el,
             "unit": "DoF/s",
             "cores": threads,
             "kind": "port",
+            "host_cpu_count": os.cpu_count(),
+            "host_cpus_usable": usable,
             "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} cells p=4 "
-            f"({sm.n_dofs} DoFs), C++ restatement oracle/asm_oracle_cpu.cc, {threads} threads",
+            f"({sm.n_dofs} DoFs, the bench mesh), C++ restatement oracle/asm_oracle_cpu.cc, {threads} threads "
+            f"(os.cpu_count()={os.cpu_count()}, usable={usable})",
         }
     nc = (12, 12, 12)
     mesh = orc.Mesh(nc, 4, [orc.DIRICHLET] * 3, mapfn=lambda pts: orc.kershaw(0.3, 0.3, pts))
@@ -97,6 +107,8 @@ def cpu_baseline(args, pkg):
         "unit": "DoF/s",
         "cores": 1,
         "kind": "port",
+        "host_cpu_count": os.cpu_count(),
+        "host_cpus_usable": usable,
         "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} Kershaw cells p=4 "
         f"({mesh.n_dofs} DoFs), numpy oracle, 1 thread",
     }
@@ -116,7 +128,7 @@ def main():
     ap.add_argument("--patch", default="cell", choices=["cell", "vertex"], help="element-centred or vertex-star patches")
     ap.add_argument("--weighting", default="post", choices=["none", "pre", "post", "symm", "ras"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (CPU share of one GPU)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,11 +142,14 @@ def main():
     pkg = load_package()
     dist = None
     if world > 1:
+        # The process group only bootstraps the library's own RCCL communicator (broadcast of the
+        # unique id) and carries the host-side barrier / max-over-ranks of the timing: gloo on CPU
+        # tensors.  The data path (ghost planes) runs over RCCL inside the library; keeping torch's
+        # NCCL backend out of the process means ONE RCCL and one HIP runtime are live in it.
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
 
     cells = args.cells
     if cells is None:
@@ -175,11 +190,10 @@ def main():
         ctx.set_keep_ghosts(True)
 
     def barrier():
+        # the library's two streams (sweeps, ghost exchange) carry all GPU work of this process:
+        # asm_synchronize waits for both (what torch.cuda.synchronize() would do for torch's streams)
         ctx.synchronize()
         if world > 1:
-            import torch
-
-            torch.cuda.synchronize()
             dist.barrier()
 
     n_dofs = ctx.n_dofs
@@ -205,7 +219,7 @@ def main():
     if world > 1:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -278,7 +292,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, pkg)
+            out["cpu_baseline"] = cpu_baseline(args, pkg, cells)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

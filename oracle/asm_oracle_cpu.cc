@@ -17,8 +17,13 @@
 //     counterpart of the reference's one-MPI-rank-per-core runs.
 // Tables (1-D basis, eigen-decompositions, weights) are computed by oracle/asm_oracle.py
 // and passed in, so this file contains the sweeps only.
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -215,43 +220,137 @@ namespace
     scatter_add(p, bt, t, dst, 1.0);
   }
 
-  // run f(batch) over all cells, colour by colour, batches split over threads
+  // Persistent worker threads (the shared-memory stand-in for the reference's one MPI rank per core):
+  // run(f) executes f(thread) on every thread and returns when all are done.  Thread t always works
+  // on the t-th slice of the cell layers AND of the vector index range, so that the pages a thread
+  // first touches (vectors are allocated uninitialised and zeroed in parallel) are the pages it
+  // mostly works on afterwards (NUMA first-touch placement).
+  class Pool
+  {
+  public:
+    explicit Pool(const int n)
+      : n_(n)
+    {
+      for (int t = 1; t < n_; ++t)
+        workers_.emplace_back([this, t]() { loop(t); });
+    }
+    ~Pool()
+    {
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        stop_ = true;
+        ++epoch_;
+      }
+      cv_.notify_all();
+      for (auto &w : workers_)
+        w.join();
+    }
+    int
+    size() const
+    {
+      return n_;
+    }
+    void
+    run(const std::function<void(int)> &f)
+    {
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        job_     = &f;
+        pending_ = n_ - 1;
+        ++epoch_;
+      }
+      cv_.notify_all();
+      f(0);
+      std::unique_lock<std::mutex> lk(m_);
+      done_.wait(lk, [this]() { return pending_ == 0; });
+    }
+
+  private:
+    void
+    loop(const int t)
+    {
+      long seen = 0;
+      for (;;)
+        {
+          const std::function<void(int)> *job;
+          {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&]() { return epoch_ != seen; });
+            seen = epoch_;
+            if (stop_)
+              return;
+            job = job_;
+          }
+          (*job)(t);
+          {
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0)
+              done_.notify_one();
+          }
+        }
+    }
+    int                             n_;
+    std::vector<std::thread>        workers_;
+    std::mutex                      m_;
+    std::condition_variable         cv_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    long                            epoch_ = 0;
+    int                             pending_ = 0;
+    bool                            stop_ = false;
+  };
+
+  // cells of one colour (2x2x2 parity: no two cells of a colour share a DoF), in SIMD batches along x,
+  // ordered by z layer; thread t takes the t-th slice of the list
+  std::vector<Batch>
+  colour_batches(const Problem &p, const int colour)
+  {
+    std::vector<Batch> batches;
+    for (int cz = (colour >> 2) & 1; cz < p.nc[2]; cz += 2)
+      for (int cy = (colour >> 1) & 1; cy < p.nc[1]; cy += 2)
+        {
+          Batch bt;
+          bt.n = 0;
+          for (int cx = colour & 1; cx < p.nc[0]; cx += 2)
+            {
+              bt.c[bt.n][0] = cx;
+              bt.c[bt.n][1] = cy;
+              bt.c[bt.n][2] = cz;
+              if (++bt.n == VL)
+                {
+                  batches.push_back(bt);
+                  bt.n = 0;
+                }
+            }
+          if (bt.n)
+            batches.push_back(bt);
+        }
+    return batches;
+  }
+
+  // run f(batch) over all cells, colour by colour, batches split over the pool's threads
   template <typename F>
   void
-  cell_loop(const Problem &p, const int n_threads, F &&f)
+  cell_loop(Pool &pool, const std::vector<Batch> (&colours)[8], F &&f)
   {
+    const int nt = pool.size();
     for (int colour = 0; colour < 8; ++colour)
       {
-        std::vector<Batch> batches;
-        for (int cz = (colour >> 2) & 1; cz < p.nc[2]; cz += 2)
-          for (int cy = (colour >> 1) & 1; cy < p.nc[1]; cy += 2)
-            {
-              Batch bt;
-              bt.n = 0;
-              for (int cx = colour & 1; cx < p.nc[0]; cx += 2)
-                {
-                  bt.c[bt.n][0] = cx;
-                  bt.c[bt.n][1] = cy;
-                  bt.c[bt.n][2] = cz;
-                  if (++bt.n == VL)
-                    {
-                      batches.push_back(bt);
-                      bt.n = 0;
-                    }
-                }
-              if (bt.n)
-                batches.push_back(bt);
-            }
-        std::vector<std::thread> pool;
-        const size_t             nb = batches.size();
-        for (int th = 0; th < n_threads; ++th)
-          pool.emplace_back([&, th]() {
-            for (size_t i = nb * th / n_threads; i < nb * (th + 1) / n_threads; ++i)
-              f(batches[i]);
-          });
-        for (auto &t : pool)
-          t.join();
+        const std::vector<Batch> &batches = colours[colour];
+        const size_t              nb      = batches.size();
+        pool.run([&](const int th) {
+          for (size_t i = nb * th / nt; i < nb * (th + 1) / nt; ++i)
+            f(batches[i]);
+        });
       }
+  }
+
+  // f(i0, i1) on the thread's slice of [0, n)
+  template <typename F>
+  void
+  vector_loop(Pool &pool, const long n, F &&f)
+  {
+    const int nt = pool.size();
+    pool.run([&](const int th) { f(n * th / nt, n * (th + 1) / nt); });
   }
 } // namespace
 
@@ -286,33 +385,53 @@ oracle_cpu_cheb_step(const int *nc, const int *periodic, const double *h, const 
   p.wpost[0] = wpost_x;
   p.wpost[1] = wpost_y;
   p.wpost[2] = wpost_z;
-  std::vector<char> con(n, 0);
-  for (int K = 0; K < p.nu[2]; ++K)
-    for (int J = 0; J < p.nu[1]; ++J)
-      for (int I = 0; I < p.nu[0]; ++I)
-        con[I + (long)p.nu[0] * (J + (long)p.nu[1] * K)] = constrained(p, 0, I) || constrained(p, 1, J) || constrained(p, 2, K);
-
-  std::vector<double> r(n), t(n), xo(n), xn(n);
+  Pool               pool(n_threads < 1 ? 1 : n_threads);
+  std::vector<Batch> colours[8];
+  for (int c = 0; c < 8; ++c)
+    colours[c] = colour_batches(p, c);
+  // work vectors: uninitialised allocations, first touched by the thread that owns the slice
+  const auto alloc = [&](const long count) { return static_cast<double *>(std::malloc(sizeof(double) * count)); };
+  double *   xw = alloc(n), *bw = alloc(n), *r = alloc(n), *t = alloc(n), *xo = alloc(n);
+  char *     con = static_cast<char *>(std::malloc(n));
+  if (!xw || !bw || !r || !t || !xo || !con)
+    return 2;
+  const long nxy = (long)p.nu[0] * p.nu[1];
+  vector_loop(pool, n, [&](const long i0, const long i1) {
+    for (long i = i0; i < i1; ++i)
+      {
+        const int K = (int)(i / nxy), J = (int)((i % nxy) / p.nu[0]), I = (int)(i % p.nu[0]);
+        con[i]      = constrained(p, 0, I) || constrained(p, 1, J) || constrained(p, 2, K);
+        xw[i]       = x[i];
+        bw[i]       = b[i];
+        r[i] = t[i] = xo[i] = 0.;
+      }
+  });
   const auto residual = [&](const double *xx) {
     // r = b - A x, identity rows on constrained DoFs (matrix_free_internal.h:247-255)
-    for (long i = 0; i < n; ++i)
-      r[i] = con[i] ? b[i] - xx[i] : b[i];
-    cell_loop(p, n_threads, [&](const Batch &bt) { laplace_batch(p, bt, xx, r.data(), -1.0); });
+    vector_loop(pool, n, [&](const long i0, const long i1) {
+      for (long i = i0; i < i1; ++i)
+        r[i] = con[i] ? bw[i] - xx[i] : bw[i];
+    });
+    cell_loop(pool, colours, [&](const Batch &bt) { laplace_batch(p, bt, xx, r, -1.0); });
   };
   const auto precondition = [&]() {
-    for (long i = 0; i < n; ++i)
-      t[i] = con[i] ? r[i] : 0.;
-    cell_loop(p, n_threads, [&](const Batch &bt) { fdm_batch(p, bt, r.data(), t.data()); });
+    vector_loop(pool, n, [&](const long i0, const long i1) {
+      for (long i = i0; i < i1; ++i)
+        t[i] = con[i] ? r[i] : 0.;
+    });
+    cell_loop(pool, colours, [&](const Batch &bt) { fdm_batch(p, bt, r, t); });
   };
   for (int rep = 0; rep < reps; ++rep)
     {
-      residual(x);
+      residual(xw);
       precondition();
-      for (long i = 0; i < n; ++i)
-        {
-          xo[i] = x[i];
-          x[i] += t[i] / theta;
-        }
+      vector_loop(pool, n, [&](const long i0, const long i1) {
+        for (long i = i0; i < i1; ++i)
+          {
+            xo[i] = xw[i];
+            xw[i] += t[i] / theta;
+          }
+      });
       double       rhok  = delta / theta;
       const double sigma = theta / delta;
       for (int k = 1; k < degree; ++k)
@@ -320,16 +439,28 @@ oracle_cpu_cheb_step(const int *nc, const int *periodic, const double *h, const 
           const double rhokp = 1. / (2. * sigma - rhok);
           const double f1 = rhokp * rhok, f2 = 2. * rhokp / delta;
           rhok = rhokp;
-          residual(x);
+          residual(xw);
           precondition();
-          for (long i = 0; i < n; ++i)
-            {
-              xn[i] = x[i] + f1 * (x[i] - xo[i]) + f2 * t[i];
-              xo[i] = x[i];
-              x[i]  = xn[i];
-            }
+          vector_loop(pool, n, [&](const long i0, const long i1) {
+            for (long i = i0; i < i1; ++i)
+              {
+                const double xn = xw[i] + f1 * (xw[i] - xo[i]) + f2 * t[i];
+                xo[i]           = xw[i];
+                xw[i]           = xn;
+              }
+          });
         }
     }
+  vector_loop(pool, n, [&](const long i0, const long i1) {
+    for (long i = i0; i < i1; ++i)
+      x[i] = xw[i];
+  });
+  std::free(xw);
+  std::free(bw);
+  std::free(r);
+  std::free(t);
+  std::free(xo);
+  std::free(con);
   return 0;
 }
 }
