@@ -24,6 +24,8 @@ GEOMETRY = {"cartesian": 0, "kershaw": 1, "q2_points": 2}
 PRECOND = {"FDM": 0, "Diagonal": 1}
 EV = {"auto": 0, "lanczos": 1, "power iteration": 2}
 KERNEL = {"auto": 0, "generic": 1, "tiled": 2}
+POLYNOMIAL = {"1st kind": 0, "4th kind": 1}
+FUSED = {"none": 0, "residual": 1, "cheb_first": 2, "relax": 3, "cheb_next": 4}
 
 
 class AsmParams(C.Structure):
@@ -49,6 +51,7 @@ class AsmParams(C.Structure):
         ("rank", C.c_int32),
         ("world_size", C.c_int32),
         ("proc_grid", C.c_int32 * 3),
+        ("polynomial_type", C.c_int32),
     ]
 
 
@@ -99,6 +102,7 @@ class AsmExchangeStep(C.Structure):
 # every symbol declared in include/dealii_asm_amd.h
 EXPORTED_SYMBOLS = [
     "asm_params_default",
+    "asm_params_set",
     "asm_create",
     "asm_destroy",
     "asm_last_error",
@@ -117,6 +121,9 @@ EXPORTED_SYMBOLS = [
     "asm_op_vmult",
     "asm_op_inverse_diagonal",
     "asm_precond_vmult",
+    "asm_op_vmult_fused",
+    "asm_precond_vmult_fused",
+    "asm_is_symmetric",
     "asm_cheb_estimate_eigenvalues",
     "asm_cheb_set_eigenvalue",
     "asm_cheb_vmult",
@@ -154,6 +161,10 @@ def load_library():
     lib.asm_last_error.argtypes = [C.c_void_p]
     lib.asm_params_default.argtypes = [C.POINTER(AsmParams)]
     lib.asm_params_default.restype = None
+    lib.asm_params_set.argtypes = [C.POINTER(AsmParams), C.c_char_p, C.c_char_p]
+    lib.asm_op_vmult_fused.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.asm_precond_vmult_fused.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+    lib.asm_is_symmetric.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_create.argtypes = [C.POINTER(AsmParams), C.POINTER(C.c_void_p)]
     lib.asm_destroy.argtypes = [C.c_void_p]
     lib.asm_destroy.restype = None
@@ -212,6 +223,8 @@ def make_params(
     rank=0,
     world_size=1,
     proc_grid=(0, 0, 0),
+    polynomial_type="1st kind",
+    options=None,
 ):
     """Fill an asm_params with the reference's key names as keyword arguments
     (include/precondition.templates.h:108-152, 195-211)."""
@@ -249,6 +262,11 @@ def make_params(
     p.stream = stream
     p.rank = rank
     p.world_size = world_size
+    p.polynomial_type = POLYNOMIAL[polynomial_type]
+    # options: {reference JSON key: string value}, applied last through asm_params_set
+    for key, value in (options or {}).items():
+        if lib.asm_params_set(C.byref(p), str(key).encode(), str(value).encode()):
+            raise ValueError(lib.asm_last_error(None).decode())
     p._keepalive = keep
     return p
 
@@ -397,6 +415,24 @@ class Context:
 
     def precond_vmult(self, dst, src):
         self._check(self.lib.asm_precond_vmult(self.handle, dst.ptr, src.ptr))
+
+    def op_vmult_fused(self, mode, dst, src, b=None):
+        """LaplaceOperatorMatrixFree::vmult(dst, src, pre, post) for the updates of asm_fused_update"""
+        self._check(self.lib.asm_op_vmult_fused(self.handle, FUSED[mode], dst.ptr, src.ptr, b.ptr if b is not None else None))
+
+    def precond_vmult_fused(self, mode, dst, src, x=None, x_old=None, f1=0.0, f2=1.0):
+        """ASPoissonPreconditioner::vmult(dst, src, pre, post) for the updates of asm_fused_update"""
+        self._check(
+            self.lib.asm_precond_vmult_fused(
+                self.handle, FUSED[mode], dst.ptr, src.ptr, x.ptr if x is not None else None,
+                x_old.ptr if x_old is not None else None, float(f1), float(f2)
+            )
+        )
+
+    def is_symmetric(self):
+        v = C.c_int32()
+        self._check(self.lib.asm_is_symmetric(self.handle, C.byref(v)))
+        return bool(v.value)
 
     def estimate_eigenvalues(self):
         lam = C.c_double()

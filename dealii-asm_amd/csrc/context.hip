@@ -67,6 +67,7 @@ struct asm_ctx
   hipStream_t              stream = nullptr;
   int                      device = 0; // HIP device ordinal every call of this context runs on
   int                      n_cu   = 0; // its compute units (tile scheduling of the tiled sweeps)
+  int                      laplace_rows = 0; // TiledArgs::rows of the tiled Laplace sweep (tune_tiled_laplace)
   DevGrid                  g;
   DevFdm                   f;
   DevOp                    op;
@@ -453,6 +454,7 @@ namespace
         a.iface[d][f] = ctx->s.face[d][f] == FACE_INTERFACE;
     a.device = ctx->device;
     a.n_cu   = ctx->n_cu;
+    a.rows   = ctx->laplace_rows;
     if (!ov && ctx->debug_two_phase)
       {
         a.phase = 1;
@@ -627,6 +629,9 @@ namespace
       }
     const int    degree = ctx->s.prm.cheb_degree;
     const double theta = ctx->theta, delta = ctx->delta;
+    const bool   fourth  = ctx->s.prm.polynomial_type == ASM_POLY_FOURTH_KIND;
+    // factor of the first update: 1/theta (1st kind), 4/(3 lambda_max) (4th kind; delta holds lambda_max)
+    const double first   = fourth ? 4. / (3. * delta) : 1. / theta;
     const bool   iterate = degree >= 2 && std::fabs(delta) >= 1e-40;
     const int    k_total = iterate ? degree : 1;
     double *     A = dst, *S = ctx->S, *R = ctx->R;
@@ -655,7 +660,7 @@ namespace
         // the final iterate lands in A if the first one goes to A for odd k, to S for even k
         cur             = (k_total % 2) ? A : S;
         ctx->last_sweep = k_total == 1;
-        err             = pc_apply(ctx, PC_FIRST, cur, const_cast<double *>(b), nullptr, nullptr, 0., 1. / theta);
+        err             = pc_apply(ctx, PC_FIRST, cur, const_cast<double *>(b), nullptr, nullptr, 0., first);
         if (err)
           return err;
         prev = nullptr;
@@ -668,9 +673,9 @@ namespace
         if (k_total == 1)
           {
             ctx->last_sweep = true;
-            return pc_apply(ctx, PC_STEP1, A, R, A, nullptr, 1., 1. / theta);
+            return pc_apply(ctx, PC_STEP1, A, R, A, nullptr, 1., first);
           }
-        err = pc_apply(ctx, PC_STEP1, S, R, A, nullptr, 1., 1. / theta);
+        err = pc_apply(ctx, PC_STEP1, S, R, A, nullptr, 1., first);
         if (err)
           return err;
         cur  = S;
@@ -680,9 +685,21 @@ namespace
     const double sigma = theta / delta;
     for (int k = 1; k < k_total; ++k)
       {
-        const double rhokp = 1. / (2. * sigma - rhok);
-        const double f1 = rhokp * rhok, f2 = 2. * rhokp / delta;
-        rhok = rhokp;
+        double f1, f2;
+        if (fourth)
+          {
+            // x_{j+1} = x_j + (2j-1)/(2j+3) (x_j - x_{j-1}) + (8j+4)/(2j+3) / lambda_max P^-1 r_j, j = k (Lottes 2022;
+            // deal.II PreconditionChebyshev, PolynomialType::fourth_kind)
+            f1 = (2. * k - 1.) / (2. * k + 3.);
+            f2 = (8. * k + 4.) / (delta * (2. * k + 3.));
+          }
+        else
+          {
+            const double rhokp = 1. / (2. * sigma - rhok);
+            f1                 = rhokp * rhok;
+            f2                 = 2. * rhokp / delta;
+            rhok               = rhokp;
+          }
         err  = op_apply(ctx, OP_RESIDUAL, R, cur, b);
         if (err)
           return err;
@@ -716,6 +733,62 @@ namespace
         else if (ctx->exchanged_vec == A)
           ctx->exchanged_vec = nullptr;
       }
+    return ASM_OK;
+  }
+
+  // The tiled Laplace sweep exists with 8 (first generation), 9, 10 and 11 cell rows per workgroup.
+  // Which is fastest depends on how the tiles fit the block and on the device (halo rows, tile
+  // quantisation, rounds of workgroups): measured once per context, two launches per candidate on the
+  // scratch vectors.  All candidates sum the contributions to a DoF in the same order: the choice
+  // does not change results.  ASM_TILED_ROWS=0|9|10|11 fixes it (experiments).
+  int
+  tune_tiled_laplace(asm_ctx *ctx)
+  {
+    if (!ctx->s.laplace_tiled)
+      return ASM_OK;
+    if (const char *env = std::getenv("ASM_TILED_ROWS"))
+      {
+        const int r = std::atoi(env);
+        ctx->laplace_rows = (r >= 9 && r <= 11) ? r : 0;
+        return ASM_OK;
+      }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int cand[4] = {0, 9, 10, 11};
+    float     ms_of[4];
+    for (int i = 0; i < 4; ++i)
+      {
+        // the residual form the Chebyshev iteration uses: dst = T, src = R, b = S (zero vectors)
+        TiledArgs a{OP_RESIDUAL, ctx->R, ctx->T, ctx->S, nullptr, nullptr, 0., 0.};
+        a.device = ctx->device;
+        a.n_cu   = ctx->n_cu;
+        a.rows   = cand[i];
+        bool ok  = true;
+        for (int rep = 0; rep < 2 && ok; ++rep) // warm-up (code object, caches, clocks)
+          ok = laplace_tiled(ctx->g, ctx->op, a, ctx->stream);
+        (void)hipEventRecord(e0, ctx->stream);
+        for (int rep = 0; rep < 4 && ok; ++rep)
+          ok = laplace_tiled(ctx->g, ctx->op, a, ctx->stream);
+        (void)hipEventRecord(e1, ctx->stream);
+        float ms = 1e30f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)
+          ok = false;
+        ms_of[i] = ok ? ms : 1e30f;
+      }
+    // the first-generation kernel unless another one is clearly (2 %) faster
+    int pick = 0;
+    float best = ms_of[0];
+    for (int i = 1; i < 4; ++i)
+      if (ms_of[i] < 0.98f * ms_of[0] && ms_of[i] < best)
+        {
+          best = ms_of[i];
+          pick = cand[i];
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ctx->laplace_rows = pick;
+    HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     return ASM_OK;
   }
 
@@ -765,6 +838,93 @@ asm_params_default(asm_params *p)
   p->stream           = nullptr;
   p->rank             = 0;
   p->world_size       = 1;
+  p->polynomial_type  = ASM_POLY_FIRST_KIND;
+}
+
+int
+asm_params_set(asm_params *p, const char *key, const char *value)
+{
+  if (p == nullptr || key == nullptr || value == nullptr)
+    return ASM_ERR_INVALID_VALUE;
+  const std::string k(key), v(value);
+  const auto        fail = [&](const std::string &what) {
+    g_create_error = what + " <" + v + "> is not known!"; // wording of precondition.templates.h:26, 130-133
+    return ASM_ERR_INVALID_VALUE;
+  };
+  const auto to_int = [&](int32_t &out) {
+    char *    end = nullptr;
+    const long x  = std::strtol(v.c_str(), &end, 10);
+    if (end == v.c_str() || *end != 0)
+      return false;
+    out = (int32_t)x;
+    return true;
+  };
+  if (k == "fe degree")
+    return to_int(p->degree) ? ASM_OK : fail("Degree");
+  if (k == "n overlap")
+    return to_int(p->n_overlap) ? ASM_OK : fail("Overlap");
+  if (k == "degree")
+    return to_int(p->cheb_degree) ? ASM_OK : fail("Chebyshev degree");
+  if (k == "smoothing range")
+    {
+      char *end          = nullptr;
+      p->smoothing_range = std::strtod(v.c_str(), &end);
+      return (end != v.c_str() && *end == 0) ? ASM_OK : fail("Smoothing range");
+    }
+  if (k == "weighting type")
+    {
+      // get_weighting_type, precondition.templates.h:11-28
+      static const char *names[] = {"none", "pre", "post", "ras", "symm"};
+      for (int i = 0; i < 5; ++i)
+        if (v == names[i])
+          {
+            p->weighting_type = i;
+            return ASM_OK;
+          }
+      return fail("Weighting type");
+    }
+  if (k == "element centric")
+    {
+      if (v == "true" || v == "1")
+        p->element_centric = 1;
+      else if (v == "false" || v == "0")
+        p->element_centric = 0;
+      else
+        return fail("Element centric");
+      return ASM_OK;
+    }
+  if (k == "type")
+    {
+      if (v == "FDM")
+        p->precond_type = ASM_PRECOND_FDM;
+      else if (v == "Diagonal")
+        p->precond_type = ASM_PRECOND_DIAGONAL;
+      else
+        return fail("Preconditioner");
+      return ASM_OK;
+    }
+  if (k == "ev algorithm")
+    {
+      if (v == "lanczos")
+        p->ev_algorithm = ASM_EV_LANCZOS;
+      else if (v == "power iteration")
+        p->ev_algorithm = ASM_EV_POWER_ITERATION;
+      else
+        return fail("Eigen-value algorithm");
+      return ASM_OK;
+    }
+  if (k == "polynomial type")
+    {
+      if (v == "1st kind")
+        p->polynomial_type = ASM_POLY_FIRST_KIND;
+      else if (v == "4th kind")
+        p->polynomial_type = ASM_POLY_FOURTH_KIND;
+      else
+        return fail("Polynomial type");
+      return ASM_OK;
+    }
+  g_create_error = "unknown option key <" + k + ">";
+  return ASM_ERR_INVALID_VALUE;
 }
 
 const char *
@@ -916,6 +1076,7 @@ asm_create(const asm_params *p, asm_ctx **out)
         }
       UP(s.eig, &f.eig);
       UP(s.eig_sym, &f.eig_sym);
+
       f.n_inst   = s.n_inst;
       f.has_pre  = s.has_pre;
       f.has_post = s.has_post;
@@ -1020,6 +1181,8 @@ asm_create(const asm_params *p, asm_ctx **out)
             return fail(err);
         }
     }
+  if ((err = tune_tiled_laplace(ctx)))
+    return fail(err);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess)
     {
       ctx->error = "device error during setup";
@@ -1235,6 +1398,62 @@ asm_precond_vmult(asm_ctx *ctx, double *dst, const double *src)
 }
 
 int
+asm_op_vmult_fused(asm_ctx *ctx, int mode, double *dst, const double *src, const double *b)
+{
+  const DeviceScope device_scope(ctx);
+  if (mode != ASM_FUSED_NONE && mode != ASM_FUSED_RESIDUAL)
+    {
+      ctx->error = "asm_op_vmult_fused: mode must be ASM_FUSED_NONE or ASM_FUSED_RESIDUAL";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (dst == src || (mode == ASM_FUSED_RESIDUAL && b == nullptr))
+    {
+      ctx->error = "asm_op_vmult_fused: dst must not alias src; ASM_FUSED_RESIDUAL needs b";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (!ctx->keep_ghosts)
+    ctx->exchanged_vec = nullptr;
+  return op_apply(ctx, mode == ASM_FUSED_RESIDUAL ? OP_RESIDUAL : OP_PLAIN, dst, const_cast<double *>(src), b);
+}
+
+int
+asm_precond_vmult_fused(asm_ctx *ctx, int mode, double *dst, const double *src, const double *x, const double *x_old, double f1,
+                        double f2)
+{
+  const DeviceScope device_scope(ctx);
+  int               m;
+  switch (mode)
+    {
+      case ASM_FUSED_NONE: m = PC_PLAIN; break;
+      case ASM_FUSED_CHEB_FIRST: m = PC_FIRST; break;
+      case ASM_FUSED_RELAX: m = PC_STEP1; break;
+      case ASM_FUSED_CHEB_NEXT: m = PC_UPDATE; break;
+      default: ctx->error = "asm_precond_vmult_fused: unknown mode"; return ASM_ERR_INVALID_VALUE;
+    }
+  if (dst == src || ((m == PC_STEP1 || m == PC_UPDATE) && x == nullptr) || (m == PC_UPDATE && x_old == nullptr))
+    {
+      ctx->error = "asm_precond_vmult_fused: dst must not alias src; the update's operand vectors must be given";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (m == PC_UPDATE && dst == x)
+    {
+      ctx->error = "asm_precond_vmult_fused: ASM_FUSED_CHEB_NEXT may alias dst with x_old, not with x";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (!ctx->keep_ghosts)
+    ctx->exchanged_vec = nullptr;
+  return pc_apply(ctx, m, dst, const_cast<double *>(src), x, x_old, f1, m == PC_PLAIN ? 1. : f2);
+}
+
+int
+asm_is_symmetric(const asm_ctx *ctx, int32_t *symmetric)
+{
+  const asm_params &prm = ctx->s.prm;
+  *symmetric = (prm.precond_type == ASM_PRECOND_DIAGONAL || prm.weighting_type == ASM_W_NONE || prm.weighting_type == ASM_W_SYMM) ? 1 : 0;
+  return ASM_OK;
+}
+
+int
 asm_cheb_set_eigenvalue(asm_ctx *ctx, double lambda_max)
 {
   if (!(lambda_max > 0.))
@@ -1247,7 +1466,8 @@ asm_cheb_set_eigenvalue(asm_ctx *ctx, double lambda_max)
   const double max_ev = 1.2 * lambda_max;
   const double min_ev = max_ev / ctx->s.prm.smoothing_range;
   ctx->theta          = 0.5 * (max_ev + min_ev);
-  ctx->delta          = 0.5 * (max_ev - min_ev);
+  // the 4th-kind polynomial only needs the upper bound: delta carries it
+  ctx->delta          = ctx->s.prm.polynomial_type == ASM_POLY_FOURTH_KIND ? max_ev : 0.5 * (max_ev - min_ev);
   ctx->ev_set         = true;
   return ASM_OK;
 }

@@ -44,6 +44,8 @@ namespace asmamd
     // host side only: the device the launch goes to and its number of compute units (no process-global caches)
     int device = 0;
     int n_cu   = 0;
+    // Laplace sweep: cell rows (waves) per workgroup of the second-generation kernel (9, 10, 11), 0 = first generation
+    int rows = 0;
   };
   bool laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st);
   bool fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st);

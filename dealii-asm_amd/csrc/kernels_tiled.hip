@@ -61,6 +61,7 @@ namespace asmamd
     constexpr int YS  = P * N1;   // doubles per y-merge slot: planes 0..3 x columns 0..4
 
     constexpr int TBUF      = 64 * N1;           // one transpose buffer (all 64 lanes write, no predicate)
+    constexpr int YBUF      = WX * YS;           // y-merge slots of one wave and layer parity
     constexpr int LDS_T     = TY * TBUF;         // one per wave
     constexpr int LDS_Y     = 2 * TY * WX * YS;  // y-merge slots, double-buffered
     constexpr int LDS_TAB   = 16 * EIG;          // eigen tables
@@ -554,6 +555,146 @@ namespace asmamd
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
                   if (mine || (((c.xd >> i) | (slow >> s)) & 1u))
+                    v[s * 5 + i] = 0.;
+            }
+        }
+    }
+
+
+    // ---------------------------------------------------------------------------
+    // Source staging, second form: only planes 1..4 of a cell layer are copied global -> LDS (8
+    // direct-to-LDS loads per wave and layer instead of 10, 8 KB instead of 10 KB per wave); plane 0
+    // is plane 4 of the layer below, which the lane still holds in registers (`top`).  Rows
+    // r = 0..19 <-> (plane 1 + r / 5, DoF row r % 5).
+    // ---------------------------------------------------------------------------
+    constexpr int G4ROWS = P * N1;                      // 20 staged rows
+    constexpr int G4N    = (G4ROWS * GCH + 63) / 64;    // wave instructions per layer (8)
+    constexpr int G4BUF  = G4N * 128;                   // doubles per wave
+    __host__ __device__ constexpr int
+    gather4_kmin(const int n)
+    {
+      return 1 + (64 * n / GCH) / N1;
+    }
+    __host__ __device__ constexpr int
+    gather4_kmax(const int n)
+    {
+      return 1 + ((64 * n + 63) / GCH < G4ROWS ? (64 * n + 63) / GCH : G4ROWS - 1) / N1;
+    }
+    constexpr int G4SEAM = 5; // the instruction that covers rows of plane 3 and of plane 4
+    static_assert(G4N == 8 && gather4_kmin(G4SEAM) == P - 1 && gather4_kmax(G4SEAM) == P, "row -> instruction map changed");
+    static_assert(gather4_kmax(G4SEAM - 1) == P - 1 && gather4_kmin(G4SEAM + 1) == P, "row -> instruction map changed");
+    static_assert(gather4_kmin(0) == 1 && gather4_kmin(1) == 1 && gather4_kmin(2) == 2 && gather4_kmin(3) == 2 && gather4_kmin(4) == 3 &&
+                    gather4_kmin(6) == 4 && gather4_kmin(7) == 4,
+                  "the base operands of gather4_issue follow gather4_kmin");
+
+    struct GatherPlan4
+    {
+      unsigned off8[G4N];
+      bool     seam_hi;
+    };
+
+    __device__ __forceinline__ void
+    gather4_plan_setup(const DevGrid &g, const int X0, const int Y0, GatherPlan4 &gp)
+    {
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      gp.seam_hi     = false;
+#pragma unroll
+      for (int n = 0; n < G4N; ++n)
+        {
+          const int q = 64 * n + lane;
+          int       r = q / GCH, cc = q - r * GCH;
+          if (r >= G4ROWS) // tail of the last instruction: any valid address
+            {
+              r  = G4ROWS - 1;
+              cc = 0;
+            }
+          const int k = 1 + r / N1, j = r % N1;
+          const int I = P * X0 + 2 * cc, J = P * (Y0 + w) + j;
+          const int       xs = g.exists(0, I) ? g.store_index(0, I) : 0;
+          const int       ys = g.exists(1, J) ? g.store_index(1, J) : 0;
+          const long long o  = (long long)ys * g.stride[1] + xs + ((n != G4SEAM && k > gather4_kmin(n)) ? g.stride[2] : 0);
+          gp.off8[n]         = (unsigned)(o * 8);
+          if (n == G4SEAM && k > gather4_kmin(n))
+            gp.seam_hi = true;
+        }
+    }
+
+    // request planes 1..4 of cell layer cz (all G4N direct-to-LDS loads of the wave); see GatherRequest::issue
+    __device__ __forceinline__ void
+    gather4_issue(const DevGrid &g, const GatherPlan4 &gp, const double *__restrict__ s, const int cz, double *Gw, const bool on)
+    {
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 1)
+      return;
+#endif
+      if (!on)
+        return;
+      const unsigned lds_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)Gw);
+      const LayerPlanes lp = layer_planes(g, cz);
+      const double *    b1 = s + lp.z[1], *b2 = s + lp.z[2], *b3 = s + lp.z[3], *b4 = s + lp.z[4];
+      const double *    b_seam = b4 < b3 ? b4 : b3;
+      const unsigned    d_lo = (unsigned)((b3 - b_seam) * 8), d_hi = (unsigned)((b4 - b_seam) * 8);
+      const unsigned    o_seam = gp.off8[G4SEAM] + (gp.seam_hi ? d_hi : d_lo);
+      unsigned          keep;
+      asm volatile("s_mov_b32 %[keep], m0\n\t"
+                   "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b1]\n\t"
+                   "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b1]\n\t"
+                   "s_add_u32 m0, %[lds], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b2]\n\t"
+                   "s_add_u32 m0, %[lds], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b2]\n\t"
+                   "s_add_u32 m0, %[lds], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v4], %[b3]\n\t"
+                   "s_add_u32 m0, %[lds], 0x1400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v5], %[bs]\n\t"
+                   "s_add_u32 m0, %[lds], 0x1800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v6], %[b4]\n\t"
+                   "s_add_u32 m0, %[lds], 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v7], %[b4]\n\t"
+                   "s_mov_b32 m0, %[keep]"
+                   : [keep] "=&s"(keep)
+                   : [lds] "s"(lds_base), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), [b4] "s"(b4), [bs] "s"(b_seam),
+                     [v0] "v"(gp.off8[0]), [v1] "v"(gp.off8[1]), [v2] "v"(gp.off8[2]), [v3] "v"(gp.off8[3]), [v4] "v"(gp.off8[4]),
+                     [v5] "v"(o_seam), [v6] "v"(gp.off8[6]), [v7] "v"(gp.off8[7])
+                   : "memory", "scc");
+    }
+
+    // plane 0 of cell layer cz straight from memory (first layer of a chunk): the lane's row, 5 columns
+    __device__ __forceinline__ void
+    load_top(const DevGrid &g, const CellLane &c, const double *__restrict__ src, const int cz, double (&top)[N1])
+    {
+      const long long off = plane_offset(g, P * cz) + c.rowoff;
+#pragma unroll
+      for (int i = 0; i < N1; ++i)
+        top[i] = src[off + i + (i == P ? c.xw4 : 0)];
+    }
+
+    // layout B (lane = y row `sub`, v[k*5 + i]): plane 0 from `top`, planes 1..4 from the staged image;
+    // afterwards `top` holds plane 4 (= plane 0 of the next layer).  MASK: constrained DoFs read as zero.
+    template <bool MASK>
+    __device__ __forceinline__ void
+    staged_read4(const DevGrid &g, const CellLane &c, const double *Gw, const int cz, double (&v)[NE], double (&top)[N1])
+    {
+      const double *base = Gw + c.sub * GROW + P * c.cl;
+#pragma unroll
+      for (int i = 0; i < N1; ++i)
+        v[i] = top[i];
+#pragma unroll
+      for (int k = 1; k < N1; ++k)
+        {
+          const double *row = base + (k - 1) * (N1 * GROW);
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            v[k * 5 + i] = row[i];
+        }
+#pragma unroll
+      for (int i = 0; i < N1; ++i)
+        top[i] = v[P * 5 + i];
+      if (MASK)
+        {
+          const unsigned zd   = (g.dirichlet(2, P * cz) ? 1u : 0u) | (g.dirichlet(2, P * cz + P) ? 16u : 0u);
+          const bool     mine = (c.yd >> c.sub) & 1u;
+          if (c.cell_xy && (mine || zd != 0u || c.xd != 0u))
+            {
+#pragma unroll
+              for (int s = 0; s < N1; ++s)
+#pragma unroll
+                for (int i = 0; i < N1; ++i)
+                  if (mine || (((c.xd >> i) | (zd >> s)) & 1u))
                     v[s * 5 + i] = 0.;
             }
         }
@@ -1218,12 +1359,129 @@ namespace asmamd
         }
     }
 
+
+    // ---------------------------------------------------------------------------
+    // Second-generation Laplace sweep: the same cell algebra and merge choreography as
+    // laplace_cart_tiled_kernel, with TYW cell rows (waves) per workgroup instead of 8, the source
+    // plane shared by two consecutive layers kept in registers (staged_read4) and a register budget of
+    // three waves per SIMD: more rows per tile mean fewer halo rows and a better fit of the tiles to
+    // the mesh, the third wave covers the latencies two waves leave exposed.
+    // ---------------------------------------------------------------------------
+    template <int TYW>
+    struct Tile2
+    {
+      static constexpr int NTW   = TYW * 64;
+      static constexpr int OYW   = TYW - 1;
+      static constexpr int L_T   = TYW * TBUF;
+      static constexpr int L_Y   = 2 * TYW * YBUF;
+      static constexpr int L_G   = TYW * G4BUF;
+      static constexpr int TOTAL = L_T + L_Y + L_G;
+      static_assert(TOTAL * sizeof(double) <= 160 * 1024, "one workgroup must fit the 160 KB LDS of a CU");
+    };
+
+    template <int MODE, int TYW>
+    __global__ void __launch_bounds__(TYW * 64)
+    laplace_cart_tiled_kernel2(const DevGrid g, const DevOp op, const TiledArgs a, const Tiling tl)
+    {
+      using T2 = Tile2<TYW>;
+      extern __shared__ __attribute__((aligned(16))) double lds[];
+      double *S_T = lds;
+      double *S_Y = S_T + T2::L_T;
+      double *S_G = S_Y + T2::L_Y;
+
+      const int b  = xcd_remap(blockIdx.x, gridDim.x);
+      const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
+      if (!workgroup_in_phase(a, tl, tx, ty, zc))
+        return;
+      const int X0 = tx * OX - 1, Y0 = ty * T2::OYW - 1;
+
+      CellLane c;
+      cell_lane_setup(g, X0, Y0, c);
+      double *Tw = S_T + c.w * TBUF;
+      double *Gw = S_G + c.w * G4BUF;
+      GatherPlan4 gp;
+      gather4_plan_setup(g, X0, Y0, gp);
+
+      const UniformMatrix Fm(op.F_ref);
+      const UniformMatrix Lm(op.lam_ref);
+
+      const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
+      const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
+      double    hx = 1., hy = 1.;
+      if (c.cell_xy)
+        {
+          hx = op.h[0][c.cx + 1];
+          hy = op.h[1][c.cy + 1];
+        }
+      const double lam_sub = op.lam_ref[c.sub];
+      const double a_xy = hy / hx, b_xy = hx / hy, g_xy = hx * hy;
+
+      double u[NE];
+      double top[N1];
+      double carry[N1] = {0., 0., 0., 0., 0.};
+      int    par       = 0;
+      gather4_issue(g, gp, a.src, z_first, Gw, true);
+      load_top(g, c, a.src, z_first, top);
+      gather_wait();
+      for (int cz = z_first; cz < Ze; ++cz)
+        {
+          const LayerPlanes lp = layer_planes(g, cz);
+          staged_read4<true>(g, c, Gw, cz, u, top);
+          gather_release();
+          const double hz    = uniform_load(op.h[2], cz + 1);
+          const double alpha = a_xy * hz, beta = b_xy * hz, gamma = g_xy / hz;
+          sweep_fast_eo<true>(u, Fm);
+          sweep_slow_eo<true>(u, Fm);
+          gather4_issue(g, gp, a.src, cz + 1, Gw, cz + 1 < Ze);
+          transpose5(u, Tw, c);
+          sweep_slow_eo<true>(u, Fm);
+          // this layer's update operands (halo layers load them too: no branch around the loads)
+          EpilogueOperands<MODE, P> ops;
+          epilogue_prefetch<MODE, P>(lp, c, a, ops);
+          {
+            const double tc = gamma * lam_sub;
+#pragma unroll
+            for (int bb = 0; bb < N1; ++bb)
+              {
+                const double tbc = fma(beta, Lm[bb], tc);
+#pragma unroll
+                for (int aa = 0; aa < N1; ++aa)
+                  u[bb * 5 + aa] *= fma(alpha, Lm[aa], tbc);
+              }
+          }
+          sweep_slow_eo<false>(u, Fm);
+          transpose5(u, Tw, c);
+          sweep_slow_eo<false>(u, Fm);
+          sweep_fast_eo<false>(u, Fm);
+          merge_xz(c, u, carry);
+          if (cz >= Zb)
+            {
+              merge_y_and_store<MODE, P>(g, lp, c, a, S_Y + par * (T2::L_Y / 2), u, P * cz, ops STAMP_ARG);
+              par ^= 1;
+            }
+          else
+            gather_wait();
+        }
+      if (Ze == g.nc[2] && g.own_hi[2] == g.nc[2] * P)
+        {
+          EpilogueOperands<MODE, 1> ops;
+          const LayerPlanes         lp = layer_planes(g, g.nc[2]);
+          epilogue_prefetch<MODE, 1>(lp, c, a, ops);
+          epilogue_prefetch_second<MODE, 1>(lp, c, a, ops);
+#pragma unroll
+          for (int i = 0; i < N1; ++i)
+            u[i] = carry[i];
+          merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (T2::L_Y / 2), u, P * g.nc[2], ops STAMP_ARG);
+        }
+    }
+
+
     Tiling
-    make_tiling(const DevGrid &g, int n_cu)
+    make_tiling(const DevGrid &g, int n_cu, const int oy = OY)
     {
       Tiling tl;
       tl.ntx = (g.nc[0] + OX - 1) / OX;
-      tl.nty = (g.nc[1] + OY - 1) / OY;
+      tl.nty = (g.nc[1] + oy - 1) / oy;
       // the last owned plane nc*p of a non-wrapped direction is produced by the tile
       // that holds cell nc-1, no extra tile needed
       const int tiles = tl.ntx * tl.nty;
@@ -1258,13 +1516,12 @@ namespace asmamd
     // (bit d of `done` = device d).  false: the attribute was refused, the launch would be rejected.
     template <typename K>
     bool
-    set_lds_limit(K kernel, std::atomic<unsigned long long> &done, const int device)
+    set_lds_limit(K kernel, std::atomic<unsigned long long> &done, const int device, const size_t bytes = LDS_TOTAL * sizeof(double))
     {
       const unsigned long long bit = 1ull << (device & 63);
       if (done.load(std::memory_order_acquire) & bit)
         return true;
-      if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(LDS_TOTAL * sizeof(double))) != hipSuccess)
+      if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
         {
           (void)hipGetLastError();
           return false;
@@ -1286,11 +1543,42 @@ namespace asmamd
     return true;
   }
 
+  template <int MODE, int TYW>
+  static bool
+  launch_laplace_tiled2(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st)
+  {
+    using T2                                      = Tile2<TYW>;
+    static std::atomic<unsigned long long> done{0};
+    const size_t                           bytes = T2::TOTAL * sizeof(double);
+    if (!set_lds_limit(laplace_cart_tiled_kernel2<MODE, TYW>, done, a.device, bytes))
+      return false;
+    const Tiling tl = make_tiling(g, a.n_cu, T2::OYW);
+    hipLaunchKernelGGL((laplace_cart_tiled_kernel2<MODE, TYW>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(T2::NTW), bytes, st, g, op, a, tl);
+    return true;
+  }
+
   bool
   laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st)
   {
     if (g.p != P || !op.cartesian)
       return false;
+    // a.rows: cell rows (waves) per workgroup; 0 = first-generation kernel (8 rows).  Which one is the
+    // fastest depends on how the tiles fit the mesh and the device: the context measures it once (context.hip)
+    if (a.rows != 0 && (a.mode == OP_PLAIN || a.mode == OP_RESIDUAL))
+      {
+        const int rows = a.rows;
+#define ASM_LAUNCH2(R)                                                  \
+  case R:                                                               \
+    return a.mode == OP_PLAIN ? launch_laplace_tiled2<OP_PLAIN, R>(g, op, a, st) : launch_laplace_tiled2<OP_RESIDUAL, R>(g, op, a, st);
+        switch (rows)
+          {
+            ASM_LAUNCH2(9)
+            ASM_LAUNCH2(10)
+            ASM_LAUNCH2(11)
+            default: return false;
+          }
+#undef ASM_LAUNCH2
+      }
     const Tiling tl = make_tiling(g, a.n_cu);
     if (a.mode == OP_PLAIN)
       return launch_laplace_tiled<OP_PLAIN>(g, op, a, tl, st);
@@ -1333,6 +1621,7 @@ namespace asmamd
         default: return false;
       }
   }
+
 
   bool
   fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st)

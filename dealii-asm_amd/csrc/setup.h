@@ -219,6 +219,18 @@ namespace asmamd
         s.error = "smoothing range must be > 1";
         return false;
       }
+    // ---- Chebyshev parameters (deal.II's smoothing_range <= 1 means "use the smallest eigenvalue of the
+    // estimate", which this path does not compute: rejected instead of dividing by it)
+    if (prm.cheb_degree < 1)
+      {
+        s.error = "Chebyshev degree must be >= 1";
+        return false;
+      }
+    if (!(prm.smoothing_range > 1.))
+      {
+        s.error = "smoothing range must be > 1";
+        return false;
+      }
     // ---- patch shape
     if (prm.n_overlap < 1)
       {

@@ -85,6 +85,28 @@ enum asm_ev_algorithm
   ASM_EV_POWER_ITERATION = 2
 };
 
+/* "polynomial type" of PreconditionChebyshev, include/precondition.templates.h:135-152 */
+enum asm_polynomial_type
+{
+  ASM_POLY_FIRST_KIND  = 0, /* "1st kind" (default) */
+  ASM_POLY_FOURTH_KIND = 1  /* "4th kind" */
+};
+
+/* The fused vector updates PreconditionChebyshev (and relaxation / multigrid drivers) hand to
+ * vmult(dst, src, pre, post) as host lambdas over index ranges (include/operator.h:1367-1430,
+ * include/matrix_free.h:960-986, MFRunner::loop include/matrix_free_internal.h:309-359).  Host code
+ * cannot run inside a GPU sweep, so the closed set of updates those lambdas carry is applied in the
+ * kernels' store phase instead: this enum is the one place where the reference's surface is narrowed. */
+enum asm_fused_update
+{
+  ASM_FUSED_NONE       = 0, /* dst = Op src                                  (constrained rows: 0)        */
+  ASM_FUSED_RESIDUAL   = 1, /* operator only:       dst = b - A src          (constrained rows: identity) */
+  ASM_FUSED_CHEB_FIRST = 2, /* preconditioner only: dst = f2 P^-1 src        (x_0 = 0)                    */
+  ASM_FUSED_RELAX      = 3, /* preconditioner only: dst = f1 x + f2 P^-1 src (damped relaxation, first
+                               Chebyshev step from x with f1 = 1)                                        */
+  ASM_FUSED_CHEB_NEXT  = 4  /* preconditioner only: dst = x + f1 (x - x_old) + f2 P^-1 src; dst may alias x_old */
+};
+
 /* kernel family used for the sweeps */
 enum asm_kernel_variant
 {
@@ -127,6 +149,9 @@ typedef struct asm_params
   int32_t rank;
   int32_t world_size;
   int32_t proc_grid[3]; /* ranks per direction, product == world_size; 0 = choose */
+
+  /* --- appended in ABI revision 2 --------------------------------------- */
+  int32_t polynomial_type; /* asm_polynomial_type, "polynomial type", default "1st kind" */
 } asm_params;
 
 /* description of the device vector layout (replaces
@@ -179,6 +204,16 @@ typedef struct asm_direct_message
 
 /* fills *p with the reference's defaults */
 void asm_params_default(asm_params *p);
+/* Sets one option by the reference's JSON key and string value (host only, no GPU):
+ *   "n overlap", "weighting type" = none|pre|post|symm|ras, "element centric" = true|false
+ *                                              (create_fdm_preconditioner, precondition.templates.h:195-211)
+ *   "type" = FDM|Diagonal, "degree" (of the Chebyshev polynomial), "smoothing range",
+ *   "ev algorithm" = lanczos|power iteration, "polynomial type" = 1st kind|4th kind
+ *                                              (create_chebyshev_preconditioner, :108-152, 481-573)
+ *   "fe degree" (the top-level "degree" of the experiment files: polynomial degree of FE_Q)
+ * Unknown keys or values return ASM_ERR_INVALID_VALUE, where the reference throws
+ * (precondition.templates.h:26, 79-81, 130-133, 148-152). */
+int asm_params_set(asm_params *p, const char *key, const char *value);
 
 /* ASPoissonPreconditioner::ASPoissonPreconditioner (include/matrix_free.h:73-894),
  * LaplaceOperatorMatrixFree::setup_mapping_and_indices (include/operator.h:490-753)
@@ -231,6 +266,18 @@ int asm_op_inverse_diagonal(asm_ctx *ctx, double *out);
  * (or DiagonalMatrix::vmult when precond_type == ASM_PRECOND_DIAGONAL) */
 int asm_precond_vmult(asm_ctx *ctx, double *dst, const double *src);
 
+/* The overloads with pre/post operations, LaplaceOperatorMatrixFree::vmult(dst, src, pre, post)
+ * (include/operator.h:1367-1430) and ASPoissonPreconditioner::vmult(dst, src, pre, post)
+ * (include/matrix_free.h:960-986), for the updates of asm_fused_update.  An external Chebyshev,
+ * relaxation or multigrid driver reaches the fused, atomics-free sweeps through these two; what
+ * asm_cheb_vmult / asm_cheb_step do internally is exactly a sequence of such calls.
+ *   b:     ASM_FUSED_RESIDUAL
+ *   x:     ASM_FUSED_RELAX, ASM_FUSED_CHEB_NEXT;  x_old: ASM_FUSED_CHEB_NEXT (dst may alias it)
+ * dst must not alias src. */
+int asm_op_vmult_fused(asm_ctx *ctx, int mode, double *dst, const double *src, const double *b);
+int asm_precond_vmult_fused(asm_ctx *ctx, int mode, double *dst, const double *src, const double *x, const double *x_old,
+                            double f1, double f2);
+
 /* PreconditionChebyshev::estimate_eigenvalues as driven by
  * include/precondition.templates.h:458-463; synchronous.  Returns the
  * largest-eigenvalue estimate (before the 1.2 safety factor). */
@@ -254,6 +301,9 @@ int asm_n_fdm_instances(const asm_ctx *ctx, int64_t *n);
 int asm_memory_consumption(const asm_ctx *ctx, int64_t *bytes);
 /* theta, delta, lambda_max of the Chebyshev polynomial in use */
 int asm_cheb_parameters(const asm_ctx *ctx, double out[3]);
+/* ASPoissonPreconditioner::is_symmetric (include/matrix_free.h:896-904): 1 for the weightings none and symm
+ * (and for the diagonal preconditioner), 0 otherwise */
+int asm_is_symmetric(const asm_ctx *ctx, int32_t *symmetric);
 /* kernel variant actually selected (asm_kernel_variant) */
 int asm_kernel_variant_in_use(const asm_ctx *ctx, int32_t *variant);
 /* hipStreamSynchronize on the context's stream */

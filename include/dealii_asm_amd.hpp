@@ -112,6 +112,64 @@ namespace asmamd
     double *       data_ = nullptr;
   };
 
+  // PreconditionerBase<VectorType>, include/preconditioners.h:725-742: vmult is pure virtual, step throws
+  // unless overridden.  A multigrid smoother wrapper (WrapperForGMG, include/precondition.h:24-78) or a
+  // Krylov solver holds a pointer to this base.
+  template <typename VectorType>
+  class PreconditionerBase
+  {
+  public:
+    using vector_type = VectorType;
+    virtual ~PreconditionerBase() = default;
+    virtual void vmult(VectorType &dst, const VectorType &src) const = 0;
+    virtual void step(VectorType &, const VectorType &) const { throw std::runtime_error("step: not implemented (ExcNotImplemented)"); }
+  };
+
+  // The fused vector update a caller hands to vmult(dst, src, update) where the reference's drivers hand
+  // pre/post lambdas (include/operator.h:1367-1430, include/matrix_free.h:960-986): a closed set
+  // (asm_fused_update) that the sweeps apply in their store phase.
+  struct FusedUpdate
+  {
+    int                 mode  = ASM_FUSED_NONE;
+    const DeviceVector *b     = nullptr; // ASM_FUSED_RESIDUAL
+    const DeviceVector *x     = nullptr; // ASM_FUSED_RELAX, ASM_FUSED_CHEB_NEXT
+    const DeviceVector *x_old = nullptr; // ASM_FUSED_CHEB_NEXT (dst may be the same vector)
+    double              f1 = 0., f2 = 1.;
+    static FusedUpdate residual(const DeviceVector &b)
+    {
+      FusedUpdate u;
+      u.mode = ASM_FUSED_RESIDUAL;
+      u.b    = &b;
+      return u;
+    }
+    static FusedUpdate cheb_first(const double f2)
+    {
+      FusedUpdate u;
+      u.mode = ASM_FUSED_CHEB_FIRST;
+      u.f2   = f2;
+      return u;
+    }
+    static FusedUpdate relax(const DeviceVector &x, const double f1, const double f2)
+    {
+      FusedUpdate u;
+      u.mode = ASM_FUSED_RELAX;
+      u.x    = &x;
+      u.f1   = f1;
+      u.f2   = f2;
+      return u;
+    }
+    static FusedUpdate cheb_next(const DeviceVector &x, const DeviceVector &x_old, const double f1, const double f2)
+    {
+      FusedUpdate u;
+      u.mode  = ASM_FUSED_CHEB_NEXT;
+      u.x     = &x;
+      u.x_old = &x_old;
+      u.f1    = f1;
+      u.f2    = f2;
+      return u;
+    }
+  };
+
   // operator concept used by Chebyshev / Krylov / mg::Matrix (include/operator.h:273-283, 755-778, 1353-1524)
   class LaplaceOperatorMatrixFree
   {
@@ -123,7 +181,14 @@ namespace asmamd
       : ctx_(ctx)
     {}
     void vmult(DeviceVector &dst, const DeviceVector &src) const { ctx_.check(asm_op_vmult(ctx_.get(), dst.data(), src.data())); }
+    // vmult(dst, src, pre, post), include/operator.h:1367-1430
+    void vmult(DeviceVector &dst, const DeviceVector &src, const FusedUpdate &u) const
+    {
+      ctx_.check(asm_op_vmult_fused(ctx_.get(), u.mode, dst.data(), src.data(), u.b ? u.b->data() : nullptr));
+    }
     void Tvmult(DeviceVector &, const DeviceVector &) const { throw std::runtime_error("Tvmult: not implemented (as in the reference)"); }
+    // the vector layout stands in for the Utilities::MPI::Partitioner (include/operator.h:1491-1498)
+    const asm_layout &get_partitioner() const { return ctx_.layout(); }
     void initialize_dof_vector(DeviceVector &v) const { v.reinit(ctx_); }
     long long m() const { return ctx_.layout().n_global_dofs; }
     void compute_inverse_diagonal(DeviceVector &diag) const
@@ -137,15 +202,31 @@ namespace asmamd
     const Context &ctx_;
   };
 
-  // PreconditionerBase shape: vmult, step (include/preconditioners.h:725-742)
-  class ASPoissonPreconditioner
+  // ASPoissonPreconditioner behind the PreconditionerBase shape (include/preconditioners.h:725-742, 897-926)
+  class ASPoissonPreconditioner : public PreconditionerBase<DeviceVector>
   {
   public:
     explicit ASPoissonPreconditioner(const Context &ctx)
       : ctx_(ctx)
     {}
-    void vmult(DeviceVector &dst, const DeviceVector &src) const { ctx_.check(asm_precond_vmult(ctx_.get(), dst.data(), src.data())); }
-    void step(DeviceVector &, const DeviceVector &) const { throw std::runtime_error("step: not implemented (as in the reference)"); }
+    void vmult(DeviceVector &dst, const DeviceVector &src) const override
+    {
+      ctx_.check(asm_precond_vmult(ctx_.get(), dst.data(), src.data()));
+    }
+    // vmult(dst, src, pre, post), include/matrix_free.h:960-986
+    void vmult(DeviceVector &dst, const DeviceVector &src, const FusedUpdate &u) const
+    {
+      ctx_.check(asm_precond_vmult_fused(ctx_.get(), u.mode, dst.data(), src.data(), u.x ? u.x->data() : nullptr,
+                                         u.x_old ? u.x_old->data() : nullptr, u.f1, u.f2));
+    }
+    // include/matrix_free.h:896-904
+    bool is_symmetric() const
+    {
+      int32_t s = 0;
+      ctx_.check(asm_is_symmetric(ctx_.get(), &s));
+      return s != 0;
+    }
+    const asm_layout &get_partitioner() const { return ctx_.layout(); } // include/matrix_free.h:994-998
     long long n_fdm_instances() const
     {
       int64_t n = 0;
@@ -163,7 +244,7 @@ namespace asmamd
     const Context &ctx_;
   };
 
-  class PreconditionChebyshev
+  class PreconditionChebyshev : public PreconditionerBase<DeviceVector>
   {
   public:
     struct EigenvalueInformation
@@ -181,8 +262,23 @@ namespace asmamd
       return {lam, 1.2 * lam};
     }
     void set_eigenvalue(const double lambda_max) const { ctx_.check(asm_cheb_set_eigenvalue(ctx_.get(), lambda_max)); }
-    void vmult(DeviceVector &dst, const DeviceVector &src) const { ctx_.check(asm_cheb_vmult(ctx_.get(), dst.data(), src.data())); }
-    void step(DeviceVector &dst, const DeviceVector &src) const { ctx_.check(asm_cheb_step(ctx_.get(), dst.data(), src.data())); }
+    void vmult(DeviceVector &dst, const DeviceVector &src) const override
+    {
+      ctx_.check(asm_cheb_vmult(ctx_.get(), dst.data(), src.data()));
+    }
+    void step(DeviceVector &dst, const DeviceVector &src) const override
+    {
+      ctx_.check(asm_cheb_step(ctx_.get(), dst.data(), src.data()));
+    }
+    // theta, delta, lambda_max of the polynomial in use
+    void parameters(double &theta, double &delta, double &lambda_max) const
+    {
+      double out[3];
+      ctx_.check(asm_cheb_parameters(ctx_.get(), out));
+      theta      = out[0];
+      delta      = out[1];
+      lambda_max = out[2];
+    }
 
   private:
     const Context &ctx_;

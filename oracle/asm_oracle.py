@@ -736,13 +736,22 @@ def lanczos_max_eigenvalue(op, prec, b, n_iterations, tol=1e-7):
 
 
 class Chebyshev:
-    """1st-kind Chebyshev smoother; vmult == zero initial guess, step == given
-    initial guess.  With fused=True the operator and preconditioner
-    act as identity on constrained DoFs, which is what the reference's
-    optimize=2 path does through the pre/post overloads."""
+    """Chebyshev smoother; vmult == zero initial guess, step == given initial guess.
+    The operator and preconditioner act as identity on constrained DoFs, which is what the
+    reference's optimize=2 path does through the pre/post overloads.
+    polynomial_type "1st kind" | "4th kind" (precondition.templates.h:135-152).  The 4th-kind
+    recurrence [deal.II PreconditionChebyshev, PolynomialType::fourth_kind; Lottes, "Optimal
+    polynomial smoothers for multigrid V-cycles", 2022, Algorithm 1] only uses the upper bound
+    lambda_max = 1.2 * estimate:
+        x_1     = x_0 + 4/(3 lambda_max) P^-1 r_0
+        x_{j+1} = x_j + (2j-1)/(2j+3) (x_j - x_{j-1}) + (8j+4)/(2j+3)/lambda_max P^-1 r_j
+    (tests/test_oracle_golden.py pins it to the closed form of the 4th-kind polynomial)."""
 
-    def __init__(self, op, prec, degree=3, smoothing_range=20.0, eig_n_iterations=40, ev_algorithm=None, lambda_max=None):
+    def __init__(self, op, prec, degree=3, smoothing_range=20.0, eig_n_iterations=40, ev_algorithm=None, lambda_max=None,
+                 polynomial_type="1st kind"):
         self.op, self.prec, self.degree = op, prec, degree
+        assert polynomial_type in ("1st kind", "4th kind")
+        self.fourth = polynomial_type == "4th kind"
         con = op.constrained
         if lambda_max is None:
             v = initial_guess(op.mesh.n_dofs, con)
@@ -756,28 +765,30 @@ class Chebyshev:
         self.max_ev = 1.2 * lambda_max  # safety factor
         self.min_ev = self.max_ev / smoothing_range
         self.theta = 0.5 * (self.max_ev + self.min_ev)
-        self.delta = 0.5 * (self.max_ev - self.min_ev)
+        self.delta = self.max_ev if self.fourth else 0.5 * (self.max_ev - self.min_ev)
 
     def _run(self, x, b, zero_start):
         op, prec = self.op, self.prec
         theta, delta = self.theta, self.delta
+        first = 4.0 / (3.0 * delta) if self.fourth else 1.0 / theta
         if zero_start:
-            x_old = None
-            x = (1.0 / theta) * prec.vmult(b, unit_constrained=True)
+            x = first * prec.vmult(b, unit_constrained=True)
         else:
             r = b - op.vmult(x, unit_constrained=True)
-            x_old = None
-            x = x + (1.0 / theta) * prec.vmult(r, unit_constrained=True)
-            x_prev0 = None
+            x = x + first * prec.vmult(r, unit_constrained=True)
         if self.degree < 2:
             return x
         rhok, sigma = delta / theta, theta / delta
         x_prev = np.zeros_like(x) if zero_start else self._x0
-        for _ in range(self.degree - 1):
-            rhokp = 1.0 / (2.0 * sigma - rhok)
-            f1 = rhokp * rhok
-            f2 = 2.0 * rhokp / delta
-            rhok = rhokp
+        for j in range(1, self.degree):
+            if self.fourth:
+                f1 = (2.0 * j - 1.0) / (2.0 * j + 3.0)
+                f2 = (8.0 * j + 4.0) / (delta * (2.0 * j + 3.0))
+            else:
+                rhokp = 1.0 / (2.0 * sigma - rhok)
+                f1 = rhokp * rhok
+                f2 = 2.0 * rhokp / delta
+                rhok = rhokp
             r = b - op.vmult(x, unit_constrained=True)
             t = prec.vmult(r, unit_constrained=True)
             x_new = x + f1 * (x - x_prev) + f2 * t

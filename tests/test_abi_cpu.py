@@ -97,3 +97,30 @@ def test_no_cpu_fallback(pkg):
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError, match="no HIP device"):
         pkg.Context(n_cells=(2, 2, 2))
+
+
+def test_params_set_accepts_reference_keys_and_rejects_unknown(pkg):
+    """asm_params_set: the reference's JSON keys (precondition.templates.h:108-152, 195-211); unknown keys and
+    values are errors, as the reference throws for them (:26, 130-133, 148-152)"""
+    import ctypes as C
+
+    lib = pkg.load_library()
+    p = pkg.AsmParams()
+    lib.asm_params_default(C.byref(p))
+    for key, value in [("n overlap", "2"), ("weighting type", "ras"), ("element centric", "false"), ("type", "Diagonal"),
+                       ("degree", "5"), ("smoothing range", "15.5"), ("ev algorithm", "power iteration"),
+                       ("polynomial type", "4th kind"), ("fe degree", "7")]:
+        assert lib.asm_params_set(C.byref(p), key.encode(), value.encode()) == 0, key
+    assert (p.n_overlap, p.weighting_type, p.element_centric, p.precond_type) == (2, pkg.WEIGHTING["ras"], 0, pkg.PRECOND["Diagonal"])
+    assert (p.cheb_degree, p.smoothing_range, p.ev_algorithm, p.polynomial_type, p.degree) == (5, 15.5, 2, 1, 7)
+    for key, value in [("weighting type", "both"), ("polynomial type", "2nd kind"), ("ev algorithm", "qr"), ("no such key", "1"),
+                       ("degree", "three")]:
+        assert lib.asm_params_set(C.byref(p), key.encode(), value.encode()) != 0, (key, value)
+        assert "not known" in lib.asm_last_error(None).decode() or "unknown option key" in lib.asm_last_error(None).decode()
+    # the Chebyshev parameter checks of the layout setup
+    q = pkg.make_params(cheb_degree=0)
+    with pytest.raises(ValueError):
+        pkg.describe_layout(q)
+    q = pkg.make_params(smoothing_range=1.0)
+    with pytest.raises(ValueError):
+        pkg.describe_layout(q)

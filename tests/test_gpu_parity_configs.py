@@ -166,3 +166,77 @@ def test_full_size_bench_workload(pkg, nc, periodic, degree):
         bv, xv = ctx.vector(b), ctx.vector(x0)
         ctx.cheb_step(xv, bv)
         assert rel(xv.get(), ref) < TOL
+
+
+# ---------------------------------------------------------------------------
+# "polynomial type" = "4th kind" (precondition.templates.h:135-152) and the fused vmult(dst, src, pre, post) surface
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("degree", [1, 2, 3, 5])
+@pytest.mark.parametrize(
+    "nc,p,bc,geometry,kernel,precond,weighting",
+    [
+        ((13, 5, 3), 4, "dirichlet", "cartesian", "tiled", "FDM", "post"),
+        ((3, 2, 2), 4, "periodic", "cartesian", "tiled", "FDM", "symm"),
+        ((6, 2, 2), 3, "dirichlet", "kershaw", "generic", "FDM", "post"),
+        ((4, 4, 4), 1, "dirichlet", "cartesian", "generic", "Diagonal", "post"),
+    ],
+)
+def test_chebyshev_fourth_kind(pkg, nc, p, bc, geometry, kernel, precond, weighting, degree):
+    mesh, ctx = make_pair(pkg, nc, p, bc, geometry, eps=(0.3, 0.3), kernel=kernel, weighting=weighting, precond=precond,
+                          cheb_degree=degree, options={"polynomial type": "4th kind"})
+    with ctx:
+        op = orc.LaplaceOperator(mesh)
+        prec = orc.ASPoissonPreconditioner(mesh, 1, weighting) if precond == "FDM" else orc.JacobiPreconditioner(op)
+        cheb = orc.Chebyshev(op, prec, degree=degree, lambda_max=1.6, polynomial_type="4th kind")
+        ctx.set_eigenvalue(1.6)
+        rng = np.random.default_rng(11)
+        b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+        bv, xv = ctx.vector(b), ctx.vector()
+        ctx.cheb_vmult(xv, bv)
+        assert rel(xv.get(), cheb.vmult(b)) < TOL
+        xv.set(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), cheb.step(x0, b)) < TOL
+
+
+@pytest.mark.parametrize(
+    "nc,p,bc,geometry,kernel,n_overlap",
+    [((13, 5, 3), 4, "dirichlet", "cartesian", "tiled", 1), ((6, 2, 2), 4, "dirichlet", "kershaw", "auto", 1),
+     ((5, 4, 3), 4, "dirichlet", "cartesian", "auto", 2), ((3, 3, 3), 2, "periodic", "cartesian", "generic", 1)],
+)
+def test_fused_overloads_reproduce_chebyshev(pkg, nc, p, bc, geometry, kernel, n_overlap):
+    """a damped relaxation and the three-term recurrence written by the caller over asm_op_vmult_fused /
+    asm_precond_vmult_fused against the oracle's Chebyshev iteration"""
+    mesh, ctx = make_pair(pkg, nc, p, bc, geometry, eps=(0.3, 0.3), kernel=kernel, n_overlap=n_overlap, cheb_degree=3)
+    with ctx:
+        op = orc.LaplaceOperator(mesh)
+        prec = orc.ASPoissonPreconditioner(mesh, n_overlap, "post")
+        cheb = orc.Chebyshev(op, prec, degree=3, lambda_max=1.8)
+        ctx.set_eigenvalue(1.8)
+        par = ctx.cheb_parameters()
+        theta, delta = par["theta"], par["delta"]
+        rng = np.random.default_rng(3)
+        b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+        bv, x, x_old, r = ctx.vector(b), ctx.vector(x0), ctx.vector(), ctx.vector()
+        ctx.op_vmult_fused("residual", r, x, b=bv)
+        ctx.precond_vmult_fused("relax", x_old, r, x=x, f1=1.0, f2=1.0 / theta)
+        x, x_old = x_old, x
+        rhok, sigma = delta / theta, theta / delta
+        for _ in range(2):
+            rhokp = 1.0 / (2.0 * sigma - rhok)
+            f1, f2, rhok = rhokp * rhok, 2.0 * rhokp / delta, rhokp
+            ctx.op_vmult_fused("residual", r, x, b=bv)
+            ctx.precond_vmult_fused("cheb_next", x_old, r, x=x, x_old=x_old, f1=f1, f2=f2)
+            x, x_old = x_old, x
+        assert rel(x.get(), cheb.step(x0, b)) < TOL
+        # plain forms and argument checks
+        y = ctx.vector()
+        ctx.op_vmult_fused("none", y, x)
+        assert rel(y.get(), op.vmult(x.get())) < TOL
+        ctx.precond_vmult_fused("cheb_first", y, bv, f2=0.5)
+        assert rel(y.get(), 0.5 * prec.vmult(b, unit_constrained=True)) < TOL
+        with pytest.raises(RuntimeError):
+            ctx.op_vmult_fused("residual", y, x)  # b missing
+        with pytest.raises(RuntimeError):
+            ctx.precond_vmult_fused("cheb_next", x, r, x=x, x_old=x_old, f1=0.1, f2=0.1)  # dst aliases x
+        assert ctx.is_symmetric() is False

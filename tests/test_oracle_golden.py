@@ -157,3 +157,40 @@ def test_patch_index_sets_match_reference_fixture():
             idx, valid = mesh.box_indices([p * cc - (n_overlap - 1) for cc in mesh.cc], m)
             got = num[idx[c][valid[c]]]
             assert list(got) == expect, (cx, cy, n_overlap)
+
+
+def test_fourth_kind_chebyshev_matches_closed_form():
+    """The error propagator of k steps of the 4th-kind Chebyshev iteration on a (preconditioned) operator with
+    spectrum in (0, lambda_max] is  W_k(1 - 2 lambda / lambda_max) / (2k + 1)  with the 4th-kind polynomial
+    W_k(cos t) = sin((k + 1/2) t) / sin(t / 2)  (Lottes 2022, eq. (23)).  Checked on a diagonal operator:
+    pins the recurrence coefficients of oracle and HIP path, which deal.II only holds upstream."""
+
+    class Diag:
+        def __init__(self, d):
+            self.d = d
+            self.constrained = np.zeros(len(d), bool)
+
+        def vmult(self, x, unit_constrained=False):
+            return self.d * x
+
+    class Ident:
+        def vmult(self, x, unit_constrained=False):
+            return x.copy()
+
+        def is_symmetric(self):
+            return True
+
+    lam_hat = 2.0
+    lam_max = 1.2 * lam_hat
+    d = np.linspace(0.05, lam_max, 57)
+    for k in (1, 2, 3, 5, 8):
+        cheb = orc.Chebyshev(Diag(d), Ident(), degree=k, lambda_max=lam_hat, polynomial_type="4th kind")
+        x = cheb.vmult(np.ones_like(d))  # x_0 = 0, b = 1: error e_k = 1/d - x_k, e_0 = 1/d
+        err_ratio = (1.0 / d - x) * d
+        t = np.arccos(1.0 - 2.0 * d / lam_max)
+        W = np.sin((k + 0.5) * t) / np.sin(0.5 * t) / (2 * k + 1)
+        assert np.allclose(err_ratio, W, rtol=1e-10, atol=1e-12), k
+        # step() from a non-zero start propagates the same polynomial
+        x0 = np.cos(np.arange(len(d)))
+        xk = cheb.step(x0, np.ones_like(d))
+        assert np.allclose((1.0 / d - xk), W * (1.0 / d - x0), rtol=1e-10, atol=1e-12), k
