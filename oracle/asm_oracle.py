@@ -795,7 +795,7 @@ class Chebyshev:
             x_prev, x = x, x_new
         return x
 
-    def vmult(self, b):
+    def vmult(self, b, unit_constrained=True):
         return self._run(None, b, True)
 
     def step(self, x, b):

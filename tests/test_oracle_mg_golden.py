@@ -1,0 +1,123 @@
+"""Pins the oracle twin of the smoother's callers (oracle/asm_oracle_mg.py: transfers, V-cycle, coarse solver,
+GMRES/CG) on the outer iteration counts printed by the reference's own regression fixtures
+tests/element_centered_preconitioners/small/*.output (2-D, p=3, 8x8 cells, f=1, GMRES to 1e-2), and checks the
+transfer operators' defining properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import asm_oracle as orc
+import asm_oracle_mg as mg
+from test_oracle_golden import power_iteration_estimate
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RUNS = json.load(open(os.path.join(HERE, "golden", "reference_small_iterations.json")))["runs"]
+P, LEVELS = 3, 3
+
+
+def _inner(mesh, op, cfg):
+    """the preconditioner named by a 'preconditioner' block of the fixtures' JSON files"""
+    t = cfg["type"]
+    if t == "Identity":
+        return mg.Identity()
+    if t == "Diagonal":
+        return orc.JacobiPreconditioner(op)
+    if t in ("FDM", "AdditiveSchwarzPreconditioner"):
+        # on Cartesian cells the matrix-based additive Schwarz with 'matrix approximation: none' is the FDM inverse
+        # (the fdm_01.cc invariant, tests/test_oracle_golden.py)
+        return orc.ASPoissonPreconditioner(mesh, int(cfg.get("n overlap", 1)), cfg.get("weighting type", "symm"))
+    raise NotImplementedError(t)
+
+
+def _chebyshev(level, mesh, op, cfg):
+    inner = cfg["preconditioner"]
+    fixture = {"precond": "Diagonal"} if inner["type"] == "Diagonal" else {
+        "n_overlap": int(inner.get("n overlap", 1)), "weighting": inner.get("weighting type", "symm")}
+    lam = power_iteration_estimate(level, fixture)  # deal.II's start vector in deal.II's numbering, 20 iterations
+    return orc.Chebyshev(op, _inner(mesh, op, inner), degree=int(cfg.get("degree", 3)), lambda_max=lam)
+
+
+def _system_preconditioner(cfg):
+    nc = (2**LEVELS,) * 2
+    bc = [orc.DIRICHLET] * 2
+    if cfg["type"] == "Multigrid":
+        assert cfg.get("mg type", "h") == "h"
+        M, meshes, ops = mg.build_multigrid(
+            nc, P, bc,
+            smoother_factory=lambda l, mesh, op: _chebyshev(l, mesh, op, cfg["mg smoother"]),
+            coarse_factory=lambda mesh, op: _chebyshev(0, mesh, op, cfg["mg coarse grid solver"]),
+        )
+        return M, meshes[-1], ops[-1]
+    mesh = orc.Mesh(nc, P, bc)
+    op = orc.LaplaceOperator(mesh)
+    if cfg["type"] == "Chebyshev":
+        return _chebyshev(LEVELS, mesh, op, cfg), mesh, op
+    return _inner(mesh, op, cfg), mesh, op
+
+
+@pytest.mark.parametrize("run", [r for r in RUNS if "amg" not in r["file"] and "pmg" not in r["file"]], ids=lambda r: r["file"])
+def test_reference_iteration_counts(run):
+    """AMG-based fixtures (dummy_amg, dummy_pmg) need Trilinos ML and are not reproducible here"""
+    prec, mesh, op = _system_preconditioner(run["preconditioner"])
+    b = mg.right_hand_side_one(mesh)
+    x, it = mg.solve_gmres(op, b, prec, rel_tol=1e-2, abs_tol=1e-10)
+    assert it == run["it"], (run["file"], it, run["it"])
+    r = b - op.vmult(x, unit_constrained=True)
+    assert np.linalg.norm(r) <= 1e-2 * np.linalg.norm(b) * (1 + 1e-10)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("kind", ["p", "h"])
+def test_transfer_properties(dim, kind):
+    """prolongation reproduces coarse polynomials at the fine nodes (nodal interpolation), restriction is its
+    transpose, constrained DoFs stay zero"""
+    nc_f = (4, 2, 2)[:dim]
+    bc = [orc.NEUMANN] * dim
+    if kind == "p":
+        mf, mc = orc.Mesh(nc_f, 4, bc), orc.Mesh(nc_f, 2, bc)
+    else:
+        mf, mc = orc.Mesh(nc_f, 2, bc), orc.Mesh(tuple(n // 2 for n in nc_f), 2, bc)
+    T = mg.Transfer(mf, mc)
+
+    def nodes(mesh):
+        b = mesh.basis
+        xs = [np.concatenate([(c + b.nodes[:-1]) / n for c in range(n)] + [[1.0]]) for n in mesh.nc]
+        g = np.meshgrid(*xs[::-1], indexing="ij")
+        return [a.reshape(-1) for a in g[::-1]]
+
+    f = lambda X: sum((d + 1.0) * x**2 - 0.3 * x for d, x in enumerate(X)) + np.prod(X, axis=0)  # noqa: E731  (degree 2 per variable)
+    assert np.allclose(T.prolongate(f(nodes(mc))), f(nodes(mf)), rtol=1e-12, atol=1e-12)
+    rng = np.random.default_rng(0)
+    xc, rf = rng.standard_normal(mc.n_dofs), rng.standard_normal(mf.n_dofs)
+    assert np.isclose(rf @ T.prolongate(xc), T.restrict(rf) @ xc, rtol=1e-12)
+    # Dirichlet: constrained DoFs neither receive nor contribute
+    bc = [orc.DIRICHLET] * dim
+    mf2, mc2 = orc.Mesh(mf.nc, mf.p, bc), orc.Mesh(mc.nc, mc.p, bc)
+    T2 = mg.Transfer(mf2, mc2)
+    assert np.all(T2.prolongate(np.ones(mc2.n_dofs))[mf2.constrained_mask()] == 0)
+    assert np.all(T2.restrict(np.ones(mf2.n_dofs))[mc2.constrained_mask()] == 0)
+
+
+def test_level_sequences():
+    assert mg.polynomial_coarsening_sequence(4) == [1, 2, 4]
+    assert mg.polynomial_coarsening_sequence(7) == [1, 3, 7]
+    assert mg.polynomial_coarsening_sequence(4, "decrease by one") == [1, 2, 3, 4]
+    assert mg.polynomial_coarsening_sequence(4, "go to one") == [1, 4]
+    assert mg.level_sequence((8, 8), 3, "h") == [((1, 1), 3), ((2, 2), 3), ((4, 4), 3), ((8, 8), 3)]
+    assert mg.level_sequence((12, 12, 12), 4, "ph") == [((3, 3, 3), 1), ((6, 6, 6), 1), ((12, 12, 12), 1), ((12, 12, 12), 2), ((12, 12, 12), 4)]
+    assert mg.level_sequence((6, 6), 4, "p") == [((6, 6), 1), ((6, 6), 2), ((6, 6), 4)]
+
+
+def test_v_cycle_with_cg_converges_3d():
+    """3-D, p=4, ph-multigrid with Chebyshev(2) + FDM smoothing and a CG coarse solve: a handful of CG iterations"""
+    bc = [orc.DIRICHLET] * 3
+    M, meshes, ops = mg.build_multigrid(
+        (4, 4, 4), 4, bc,
+        smoother_factory=lambda l, mesh, op: orc.Chebyshev(op, orc.ASPoissonPreconditioner(mesh, 1, "symm"), degree=2),
+        coarse_factory=lambda mesh, op: mg.CoarseCG(op, rel_tol=1e-4), mg_type="ph")
+    b = mg.right_hand_side_one(meshes[-1])
+    x, it = mg.solve_cg(ops[-1], b, M, rel_tol=1e-8, abs_tol=0.0)
+    assert it <= 12
+    assert np.linalg.norm(b - ops[-1].vmult(x, unit_constrained=True)) <= 1e-8 * np.linalg.norm(b)
