@@ -26,6 +26,11 @@ EV = {"auto": 0, "lanczos": 1, "power iteration": 2}
 KERNEL = {"auto": 0, "generic": 1, "tiled": 2}
 POLYNOMIAL = {"1st kind": 0, "4th kind": 1}
 FUSED = {"none": 0, "residual": 1, "cheb_first": 2, "relax": 3, "cheb_next": 4}
+MG_TYPE = {"h": 0, "p": 1, "hp": 2, "ph": 3}
+MG_P_SEQUENCE = {"bisect": 0, "decrease by one": 1, "go to one": 2}
+MG_COARSE = {"smoother": 0, "cg": 1}
+SOLVER = {"CG": 0, "GMRES": 1}
+SYSTEM_PRECONDITIONER = {"Identity": 0, "inner": 1, "Chebyshev": 2, "Multigrid": 3}
 
 
 class AsmParams(C.Structure):
@@ -99,6 +104,38 @@ class AsmExchangeStep(C.Structure):
     ]
 
 
+class AsmMgParams(C.Structure):
+    _fields_ = [
+        ("mg_type", C.c_int32),
+        ("p_sequence", C.c_int32),
+        ("one_sided_v_cycle", C.c_int32),
+        ("coarse_solver", C.c_int32),
+        ("coarse_rel_tolerance", C.c_double),
+        ("coarse_max_iterations", C.c_int32),
+        ("estimate_eigenvalues", C.c_int32),
+    ]
+
+
+class AsmSolverParams(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32),
+        ("max_iterations", C.c_int32),
+        ("abs_tolerance", C.c_double),
+        ("rel_tolerance", C.c_double),
+        ("right_preconditioning", C.c_int32),
+        ("max_n_tmp_vectors", C.c_int32),
+    ]
+
+
+class AsmSolverResult(C.Structure):
+    _fields_ = [
+        ("n_iterations", C.c_int32),
+        ("converged", C.c_int32),
+        ("initial_residual", C.c_double),
+        ("final_residual", C.c_double),
+    ]
+
+
 # every symbol declared in include/dealii_asm_amd.h
 EXPORTED_SYMBOLS = [
     "asm_params_default",
@@ -141,6 +178,23 @@ EXPORTED_SYMBOLS = [
     "asm_debug_exchange_all",
     "asm_profile_enable",
     "asm_profile_get",
+    "asm_vec_dot",
+    "asm_vec_axpby",
+    "asm_vec_scale",
+    "asm_vec_copy",
+    "asm_vec_zero",
+    "asm_vec_constraints_set_zero",
+    "asm_mg_params_default",
+    "asm_mg_create",
+    "asm_mg_destroy",
+    "asm_mg_last_error",
+    "asm_mg_n_levels",
+    "asm_mg_level_context",
+    "asm_mg_prolongate_add",
+    "asm_mg_restrict",
+    "asm_mg_vmult",
+    "asm_solver_params_default",
+    "asm_solve",
 ]
 
 _lib = None
@@ -195,6 +249,27 @@ def load_library():
     lib.asm_debug_exchange_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int]
     lib.asm_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.asm_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    lib.asm_vec_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.asm_vec_axpby.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double]
+    lib.asm_vec_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    lib.asm_vec_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.asm_vec_zero.argtypes = [C.c_void_p, C.c_void_p]
+    lib.asm_vec_constraints_set_zero.argtypes = [C.c_void_p, C.c_void_p]
+    lib.asm_mg_params_default.argtypes = [C.POINTER(AsmMgParams)]
+    lib.asm_mg_params_default.restype = None
+    lib.asm_mg_create.argtypes = [C.POINTER(AsmParams), C.POINTER(AsmMgParams), C.POINTER(C.c_void_p)]
+    lib.asm_mg_destroy.argtypes = [C.c_void_p]
+    lib.asm_mg_destroy.restype = None
+    lib.asm_mg_last_error.argtypes = [C.c_void_p]
+    lib.asm_mg_last_error.restype = C.c_char_p
+    lib.asm_mg_n_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.asm_mg_level_context.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.asm_mg_prolongate_add.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.asm_mg_restrict.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.asm_mg_vmult.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.asm_solver_params_default.argtypes = [C.POINTER(AsmSolverParams)]
+    lib.asm_solver_params_default.restype = None
+    lib.asm_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(AsmSolverParams), C.c_void_p, C.c_void_p, C.POINTER(AsmSolverResult)]
     lib.asm_comm_unique_id.argtypes = [C.c_char_p]
     lib.asm_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     _lib = lib
@@ -353,14 +428,19 @@ class DeviceVector:
 class Context:
     """Operator + preconditioner + Chebyshev smoother on one GPU."""
 
-    def __init__(self, params: AsmParams | None = None, **kw):
+    def __init__(self, params: AsmParams | None = None, _borrowed_handle=None, **kw):
         self.lib = load_library()
-        self.params = params if params is not None else make_params(**kw)
-        h = C.c_void_p()
-        err = self.lib.asm_create(C.byref(self.params), C.byref(h))
-        if err:
-            raise RuntimeError(f"asm_create failed ({err}): {self.lib.asm_last_error(None).decode()}")
-        self.handle = h
+        self._owned = _borrowed_handle is None
+        if _borrowed_handle is not None:  # a level of a Multigrid object: owned by it
+            self.params = None
+            self.handle = _borrowed_handle
+        else:
+            self.params = params if params is not None else make_params(**kw)
+            h = C.c_void_p()
+            err = self.lib.asm_create(C.byref(self.params), C.byref(h))
+            if err:
+                raise RuntimeError(f"asm_create failed ({err}): {self.lib.asm_last_error(None).decode()}")
+            self.handle = h
         self.layout = AsmLayout()
         self._check(self.lib.asm_vector_layout(self.handle, C.byref(self.layout)))
 
@@ -369,15 +449,53 @@ class Context:
             raise RuntimeError(f"dealii_asm_amd error {err}: {self.lib.asm_last_error(self.handle).decode()}")
 
     def close(self):
-        if self.handle is not None:
+        if self.handle is not None and self._owned:
             self.lib.asm_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __enter__(self):
         return self
 
     def __exit__(self, *a):
         self.close()
+
+    # -- vector algebra (LinearAlgebra::distributed::Vector operations of the solvers) -----------
+    def vec_dot(self, x, y):
+        out = C.c_double()
+        self._check(self.lib.asm_vec_dot(self.handle, x.ptr, y.ptr, C.byref(out)))
+        return out.value
+
+    def vec_axpby(self, y, a, x, b):
+        self._check(self.lib.asm_vec_axpby(self.handle, y.ptr, float(a), x.ptr, float(b)))
+
+    def vec_scale(self, y, a, x):
+        self._check(self.lib.asm_vec_scale(self.handle, y.ptr, float(a), x.ptr))
+
+    def vec_copy(self, y, x):
+        self._check(self.lib.asm_vec_copy(self.handle, y.ptr, x.ptr))
+
+    def vec_zero(self, y):
+        self._check(self.lib.asm_vec_zero(self.handle, y.ptr))
+
+    def constraints_set_zero(self, y):
+        self._check(self.lib.asm_vec_constraints_set_zero(self.handle, y.ptr))
+
+    def solve(self, x, b, solver="GMRES", preconditioner="Chebyshev", mg=None, rel_tol=1e-2, abs_tol=1e-10, max_iter=1000,
+              right_preconditioning=True, max_n_tmp_vectors=30):
+        """solve() of element_centered_preconditioners_01.cc:108-263 (x = 0 initially); returns AsmSolverResult"""
+        sp = AsmSolverParams()
+        self.lib.asm_solver_params_default(C.byref(sp))
+        sp.type = SOLVER[solver]
+        sp.rel_tolerance, sp.abs_tolerance, sp.max_iterations = rel_tol, abs_tol, max_iter
+        sp.right_preconditioning = 1 if right_preconditioning else 0
+        sp.max_n_tmp_vectors = max_n_tmp_vectors
+        res = AsmSolverResult()
+        err = self.lib.asm_solve(self.handle, mg.handle if mg is not None else None, SYSTEM_PRECONDITIONER[preconditioner],
+                                 C.byref(sp), x.ptr, b.ptr, C.byref(res))
+        if err:
+            msg = self.lib.asm_mg_last_error(mg.handle).decode() if mg is not None else self.lib.asm_last_error(self.handle).decode()
+            raise RuntimeError(f"asm_solve failed ({err}): {msg}")
+        return res
 
     # -- vectors ------------------------------------------------------------
     def vector(self, host_owned=None):
@@ -496,6 +614,64 @@ class Context:
 
     def comm_init(self, unique_id: bytes):
         self._check(self.lib.asm_comm_init(self.handle, unique_id))
+
+
+class Multigrid:
+    """Level hierarchy + V-cycle (PreconditionerGMG, include/multigrid.h:40-520) over contexts of this library."""
+
+    def __init__(self, fine_params: AsmParams, mg_type="h", p_sequence="bisect", one_sided=False, coarse="cg",
+                 coarse_rel_tol=1e-3, coarse_max_iter=200, estimate_eigenvalues=True):
+        self.lib = load_library()
+        mp = AsmMgParams()
+        self.lib.asm_mg_params_default(C.byref(mp))
+        mp.mg_type, mp.p_sequence = MG_TYPE[mg_type], MG_P_SEQUENCE[p_sequence]
+        mp.one_sided_v_cycle = 1 if one_sided else 0
+        mp.coarse_solver = MG_COARSE[coarse]
+        mp.coarse_rel_tolerance, mp.coarse_max_iterations = coarse_rel_tol, coarse_max_iter
+        mp.estimate_eigenvalues = 1 if estimate_eigenvalues else 0
+        h = C.c_void_p()
+        err = self.lib.asm_mg_create(C.byref(fine_params), C.byref(mp), C.byref(h))
+        if err:
+            raise RuntimeError(f"asm_mg_create failed ({err}): {self.lib.asm_mg_last_error(None).decode()}")
+        self.handle = h
+        n = C.c_int32()
+        self.lib.asm_mg_n_levels(h, C.byref(n))
+        self.n_levels = n.value
+        self.levels = []
+        for l in range(self.n_levels):
+            ch = C.c_void_p()
+            self._check(self.lib.asm_mg_level_context(h, l, C.byref(ch)))
+            self.levels.append(Context(_borrowed_handle=ch))
+
+    def _check(self, err):
+        if err:
+            raise RuntimeError(f"dealii_asm_amd multigrid error {err}: {self.lib.asm_mg_last_error(self.handle).decode()}")
+
+    @property
+    def fine(self):
+        return self.levels[-1]
+
+    def prolongate_add(self, level, dst_fine, src_coarse):
+        self._check(self.lib.asm_mg_prolongate_add(self.handle, level, dst_fine.ptr, src_coarse.ptr))
+
+    def restrict(self, level, dst_coarse, src_fine):
+        self._check(self.lib.asm_mg_restrict(self.handle, level, dst_coarse.ptr, src_fine.ptr))
+
+    def vmult(self, dst, src):
+        self._check(self.lib.asm_mg_vmult(self.handle, dst.ptr, src.ptr))
+
+    def close(self):
+        if self.handle is not None:
+            for c in self.levels:
+                c.handle = None
+            self.lib.asm_mg_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def comm_unique_id() -> bytes:

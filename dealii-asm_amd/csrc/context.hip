@@ -1361,6 +1361,64 @@ asm_compress_add(asm_ctx *ctx, double *v)
 }
 
 int
+asm_vec_dot(asm_ctx *ctx, const double *x, const double *y, double *result)
+{
+  const DeviceScope device_scope(ctx);
+  return dot(ctx, x, y, result);
+}
+
+// elementwise updates also rewrite the ghost planes: a vector marked as exchanged stays consistent only
+// if every operand was, which the library does not track - drop the marker of the written vector
+int
+asm_vec_axpby(asm_ctx *ctx, double *y, double a, const double *x, double b)
+{
+  const DeviceScope device_scope(ctx);
+  if (y == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
+  vec_axpby(y, a, x, b, ctx->s.n_alloc, ctx->stream);
+  return launch_status(ctx, "asm_vec_axpby");
+}
+
+int
+asm_vec_scale(asm_ctx *ctx, double *y, double a, const double *x)
+{
+  const DeviceScope device_scope(ctx);
+  if (y == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
+  vec_scale(y, x, a, ctx->s.n_alloc, ctx->stream);
+  return launch_status(ctx, "asm_vec_scale");
+}
+
+int
+asm_vec_copy(asm_ctx *ctx, double *y, const double *x)
+{
+  const DeviceScope device_scope(ctx);
+  if (y == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
+  if (y != x)
+    HIP_TRY(hipMemcpyAsync(y, x, ctx->s.n_alloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return ASM_OK;
+}
+
+int
+asm_vec_zero(asm_ctx *ctx, double *y)
+{
+  const DeviceScope device_scope(ctx);
+  if (y == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
+  HIP_TRY(hipMemsetAsync(y, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+  return ASM_OK;
+}
+
+int
+asm_vec_constraints_set_zero(asm_ctx *ctx, double *y)
+{
+  const DeviceScope device_scope(ctx);
+  vec_constrained(ctx->g, 0, y, nullptr, nullptr, ctx->stream);
+  return launch_status(ctx, "asm_vec_constraints_set_zero");
+}
+
+int
 asm_op_vmult(asm_ctx *ctx, double *dst, const double *src)
 {
   const DeviceScope device_scope(ctx);

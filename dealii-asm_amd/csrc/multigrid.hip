@@ -1,0 +1,912 @@
+// The smoother's callers: level hierarchy, transfer operators, multigrid V-cycle, coarse
+// solver and the outer Krylov solvers, on top of the library's own C ABI (every level operator /
+// smoother is an asm_ctx; nothing here reaches into a context).
+//
+// Reference:
+//   include/multigrid.h:260-472                           PreconditionerGMG::do_update / vmult
+//   include/precondition.h:82-186                         MyMultigrid (smoother / coarse solver factories)
+//   element_centered_preconditioners_01.cc:540-740        level construction
+//   element_centered_preconditioners_01.cc:108-263        solve()
+//   transfer_01.likwid.cc:21-137                          MGTwoLevelTransfer between two operators
+// and, inside deal.II, Multigrid::level_v_step, MGTransferGlobalCoarsening, SolverCG, SolverGMRES.
+//
+// Transfers: both levels are tensor-product spaces on nested structured meshes, so the prolongation is
+// the Kronecker product of three 1-D nodal interpolation matrices (rows: fine nodes, columns: the
+// coarse basis functions of the coarse cell that contains the node).  Prolongation gathers per fine
+// DoF, restriction (the transpose) gathers per coarse DoF over the fine nodes in the support of its
+// basis function: no atomics, every entry written once.
+#include "../../include/dealii_asm_amd.h"
+#include "numerics.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace asmamd;
+
+namespace
+{
+  thread_local std::string g_mg_create_error;
+
+  constexpr int MAX_N1C = 8;  // coarse nodes per cell and direction (degree <= 7)
+  constexpr int MAX_SUP = 15; // fine nodes in the 1-D support of a coarse basis function (2 * 7 + 1)
+
+  // 1-D tables of one direction (device pointers)
+  struct Transfer1D
+  {
+    // prolongation: fine logical index I -> first coarse logical index and n1c weights
+    const int *   p_start;
+    const double *p_val; // [n_fine][MAX_N1C]
+    // restriction: coarse logical index J -> first fine logical index, count and weights
+    const int *   r_start;
+    const int *   r_count;
+    const double *r_val; // [n_coarse][MAX_SUP]
+    int           n_fine, n_coarse, n1c;
+  };
+  struct BoxLayout
+  {
+    int       begin[3]; // first stored logical coordinate
+    int       size[3];  // owned planes [0, size)
+    long long stride[3];
+  };
+  struct TransferArgs
+  {
+    Transfer1D d[3];
+    BoxLayout  fine, coarse;
+  };
+
+  __device__ __forceinline__ long long
+  box_offset(const BoxLayout &b, const int I, const int J, const int K)
+  {
+    return (I - b.begin[0]) * b.stride[0] + (J - b.begin[1]) * b.stride[1] + (K - b.begin[2]) * b.stride[2];
+  }
+
+  // dst_fine += P src_coarse: one thread per fine DoF
+  __global__ void __launch_bounds__(256)
+  prolongate_add_kernel(const TransferArgs t, double *__restrict__ dst, const double *__restrict__ src)
+  {
+    const long long n = (long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2];
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
+      {
+        const int I = (int)(e % t.fine.size[0]), J = (int)((e / t.fine.size[0]) % t.fine.size[1]),
+                  K = (int)(e / ((long long)t.fine.size[0] * t.fine.size[1]));
+        const int     cx = t.d[0].p_start[I], cy = t.d[1].p_start[J], cz = t.d[2].p_start[K];
+        const double *wx = t.d[0].p_val + (long long)I * MAX_N1C, *wy = t.d[1].p_val + (long long)J * MAX_N1C,
+                     *wz = t.d[2].p_val + (long long)K * MAX_N1C;
+        double sum = 0.;
+        for (int c = 0; c < t.d[2].n1c; ++c)
+          {
+            double sy = 0.;
+            for (int b = 0; b < t.d[1].n1c; ++b)
+              {
+                const double *row = src + box_offset(t.coarse, cx, cy + b, cz + c);
+                double        sx  = 0.;
+                for (int a = 0; a < t.d[0].n1c; ++a)
+                  sx = fma(wx[a], row[a * t.coarse.stride[0]], sx);
+                sy = fma(wy[b], sx, sy);
+              }
+            sum = fma(wz[c], sy, sum);
+          }
+        dst[box_offset(t.fine, I, J, K)] += sum;
+      }
+  }
+
+  // dst_coarse = P^T src_fine: one thread per coarse DoF
+  __global__ void __launch_bounds__(256)
+  restrict_kernel(const TransferArgs t, double *__restrict__ dst, const double *__restrict__ src)
+  {
+    const long long n = (long long)t.coarse.size[0] * t.coarse.size[1] * t.coarse.size[2];
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
+      {
+        const int I = (int)(e % t.coarse.size[0]), J = (int)((e / t.coarse.size[0]) % t.coarse.size[1]),
+                  K = (int)(e / ((long long)t.coarse.size[0] * t.coarse.size[1]));
+        const int     fx = t.d[0].r_start[I], fy = t.d[1].r_start[J], fz = t.d[2].r_start[K];
+        const int     nx = t.d[0].r_count[I], ny = t.d[1].r_count[J], nz = t.d[2].r_count[K];
+        const double *wx = t.d[0].r_val + (long long)I * MAX_SUP, *wy = t.d[1].r_val + (long long)J * MAX_SUP,
+                     *wz = t.d[2].r_val + (long long)K * MAX_SUP;
+        double sum = 0.;
+        for (int c = 0; c < nz; ++c)
+          {
+            double sy = 0.;
+            for (int b = 0; b < ny; ++b)
+              {
+                const double *row = src + box_offset(t.fine, fx, fy + b, fz + c);
+                double        sx  = 0.;
+                for (int a = 0; a < nx; ++a)
+                  sx = fma(wx[a], row[a * t.fine.stride[0]], sx);
+                sy = fma(wy[b], sx, sy);
+              }
+            sum = fma(wz[c], sy, sum);
+          }
+        dst[box_offset(t.coarse, I, J, K)] = sum;
+      }
+  }
+
+  struct Level
+  {
+    asm_params params;
+    asm_ctx *  ctx = nullptr;
+    asm_layout layout;
+    double *   x = nullptr, *b = nullptr, *r = nullptr; // solution, defect, work vector
+    // transfer to the next coarser level (levels >= 1)
+    TransferArgs        transfer;
+    std::vector<void *> allocs;
+  };
+} // namespace
+
+struct asm_mg
+{
+  asm_mg_params      mp;
+  std::vector<Level> levels;
+  hipStream_t        stream = nullptr;
+  int                device = 0;
+  // coarse CG work vectors (level 0)
+  double *    cg_p = nullptr, *cg_z = nullptr, *cg_q = nullptr;
+  std::string error;
+};
+
+namespace
+{
+  struct DeviceGuard
+  {
+    int  prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const int device)
+    {
+      if (hipGetDevice(&prev) == hipSuccess && prev != device)
+        switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+      if (switched)
+        (void)hipSetDevice(prev);
+    }
+  };
+
+#define MG_TRY(expr)                                                       \
+  do                                                                       \
+    {                                                                      \
+      const int e_ = (expr);                                               \
+      if (e_ != ASM_OK)                                                    \
+        return e_;                                                         \
+    }                                                                      \
+  while (0)
+// a call into a level context: on failure carry its message
+#define MG_CTX(mg_, ctx_, expr)                                            \
+  do                                                                       \
+    {                                                                      \
+      const int e_ = (expr);                                               \
+      if (e_ != ASM_OK)                                                    \
+        {                                                                  \
+          (mg_)->error = asm_last_error(ctx_);                             \
+          return e_;                                                       \
+        }                                                                  \
+    }                                                                      \
+  while (0)
+
+  template <typename T>
+  bool
+  upload(Level &lv, const std::vector<T> &h, const T **d)
+  {
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess)
+      return false;
+    lv.allocs.push_back(p);
+    if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+      return false;
+    *d = (const T *)p;
+    return true;
+  }
+
+  std::vector<int>
+  polynomial_sequence(const int p, const int kind)
+  {
+    // MGTransferGlobalCoarseningTools::create_polynomial_coarsening_sequence (deal.II): ascending
+    std::vector<int> seq = {p};
+    while (seq.back() > 1)
+      {
+        const int q = seq.back();
+        seq.push_back(kind == ASM_MG_BISECT ? std::max(q / 2, 1) : (kind == ASM_MG_DECREASE_BY_ONE ? q - 1 : 1));
+      }
+    std::reverse(seq.begin(), seq.end());
+    return seq;
+  }
+
+  struct LevelSpec
+  {
+    int nc[3], p;
+    bool operator==(const LevelSpec &o) const { return nc[0] == o.nc[0] && nc[1] == o.nc[1] && nc[2] == o.nc[2] && p == o.p; }
+  };
+
+  // element_centered_preconditioners_01.cc:640-672; a level the 'ph' / 'hp' lists name twice is kept once
+  std::vector<LevelSpec>
+  level_sequence(const asm_params &fine, const asm_mg_params &mp)
+  {
+    const std::vector<int>          degs = polynomial_sequence(fine.degree, mp.p_sequence);
+    std::vector<std::array<int, 3>> meshes = {{fine.n_cells[0], fine.n_cells[1], fine.n_cells[2]}};
+    // create_geometric_coarsening_sequence on a structured box: halve while every direction is even
+    while (meshes.back()[0] % 2 == 0 && meshes.back()[1] % 2 == 0 && meshes.back()[2] % 2 == 0)
+      meshes.push_back({meshes.back()[0] / 2, meshes.back()[1] / 2, meshes.back()[2] / 2});
+    std::reverse(meshes.begin(), meshes.end());
+    std::vector<LevelSpec> lv;
+    const auto             add = [&](const std::array<int, 3> &m, const int p) {
+      const LevelSpec s{{m[0], m[1], m[2]}, p};
+      if (lv.empty() || !(lv.back() == s))
+        lv.push_back(s);
+    };
+    switch (mp.mg_type)
+      {
+        case ASM_MG_H:
+          for (const auto &m : meshes)
+            add(m, degs.back());
+          break;
+        case ASM_MG_P:
+          for (const int p : degs)
+            add(meshes.back(), p);
+          break;
+        case ASM_MG_HP:
+          for (const int p : degs)
+            add(meshes.front(), p);
+          for (const auto &m : meshes)
+            add(m, degs.back());
+          break;
+        default: // ASM_MG_PH
+          for (const auto &m : meshes)
+            add(m, degs.front());
+          for (const int p : degs)
+            add(meshes.back(), p);
+      }
+    return lv;
+  }
+
+  // 1-D interpolation tables between two levels in direction d (host), then uploaded
+  bool
+  build_transfer_1d(Level &lv, const asm_params &pf, const asm_params &pc, const int d, Transfer1D &out, std::string &error)
+  {
+    const int ncf = pf.n_cells[d], ncc = pc.n_cells[d], degf = pf.degree, degc = pc.degree;
+    int       ratio = 1;
+    if (ncf != ncc)
+      {
+        if (ncf != 2 * ncc || degf != degc)
+          {
+            error = "transfer: levels are neither p- nor h-nested";
+            return false;
+          }
+        ratio = 2;
+      }
+    if (pf.boundary[d][0] == ASM_BC_PERIODIC)
+      {
+        error = "multigrid transfers support non-periodic directions only";
+        return false;
+      }
+    const int                 nf = ncf * degf + 1, nc = ncc * degc + 1, n1f = degf + 1, n1c = degc + 1;
+    const std::vector<double> nodes_f = gauss_lobatto(n1f), nodes_c = gauss_lobatto(n1c);
+    const auto constrained = [&](const asm_params &p, const int n, const int I) {
+      return (I == 0 && p.boundary[d][0] == ASM_BC_DIRICHLET) || (I == n - 1 && p.boundary[d][1] == ASM_BC_DIRICHLET);
+    };
+    // dense 1-D matrix P[I][J] (small: built once per level pair)
+    std::vector<double> P((size_t)nf * nc, 0.);
+    std::vector<int>    p_start(nf, 0);
+    for (int cf = 0; cf < ncf; ++cf)
+      {
+        const int           cc = cf / ratio, s = cf % ratio;
+        std::vector<double> xi(n1f), V, D;
+        for (int i = 0; i < n1f; ++i)
+          xi[i] = (s + nodes_f[i]) / ratio;
+        lagrange_eval(nodes_c, xi, V, D);
+        // shared fine nodes get the same row from both cells; take the lower cell for all but the last node
+        for (int i = 0; i < n1f; ++i)
+          {
+            const int I = degf * cf + i;
+            if (i == n1f - 1 && cf + 1 < ncf)
+              continue;
+            p_start[I] = degc * cc;
+            for (int j = 0; j < n1c; ++j)
+              P[(size_t)I * nc + degc * cc + j] = V[i * n1c + j];
+          }
+      }
+    for (int I = 0; I < nf; ++I)
+      for (int J = 0; J < nc; ++J)
+        if (constrained(pf, nf, I) || constrained(pc, nc, J))
+          P[(size_t)I * nc + J] = 0.;
+    std::vector<double> p_val((size_t)nf * MAX_N1C, 0.);
+    for (int I = 0; I < nf; ++I)
+      for (int j = 0; j < n1c; ++j)
+        p_val[(size_t)I * MAX_N1C + j] = P[(size_t)I * nc + p_start[I] + j];
+    std::vector<int>    r_start(nc, 0), r_count(nc, 0);
+    std::vector<double> r_val((size_t)nc * MAX_SUP, 0.);
+    for (int J = 0; J < nc; ++J)
+      {
+        int lo = nf, hi = -1;
+        for (int I = 0; I < nf; ++I)
+          if (P[(size_t)I * nc + J] != 0.)
+            {
+              lo = std::min(lo, I);
+              hi = std::max(hi, I);
+            }
+        if (hi < lo)
+          continue;
+        if (hi - lo + 1 > MAX_SUP)
+          {
+            error = "transfer: support of a coarse basis function exceeds the table width";
+            return false;
+          }
+        r_start[J] = lo;
+        r_count[J] = hi - lo + 1;
+        for (int I = lo; I <= hi; ++I)
+          r_val[(size_t)J * MAX_SUP + I - lo] = P[(size_t)I * nc + J];
+      }
+    out.n_fine   = nf;
+    out.n_coarse = nc;
+    out.n1c      = n1c;
+    if (!upload(lv, p_start, &out.p_start) || !upload(lv, p_val, &out.p_val) || !upload(lv, r_start, &out.r_start) ||
+        !upload(lv, r_count, &out.r_count) || !upload(lv, r_val, &out.r_val))
+      {
+        error = "transfer: device allocation failed";
+        return false;
+      }
+    return true;
+  }
+
+  BoxLayout
+  box_of(const asm_layout &l)
+  {
+    BoxLayout b;
+    for (int d = 0; d < 3; ++d)
+      {
+        b.begin[d]  = l.store_begin[d];
+        b.size[d]   = l.owned_size[d];
+        b.stride[d] = l.stride[d];
+      }
+    return b;
+  }
+
+  int
+  launch_blocks(const long long n)
+  {
+    return (int)std::min<long long>(std::max<long long>((n + 255) / 256, 1), 1 << 16);
+  }
+
+  int
+  check_launch(asm_mg *mg, const char *what)
+  {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+      return ASM_OK;
+    mg->error = std::string("kernel launch failed in ") + what + ": " + hipGetErrorString(e);
+    return ASM_ERR_DEVICE;
+  }
+
+  // ---- Krylov solvers on one context --------------------------------------------------------------
+  // Vectors the solvers see have zeros on constrained DoFs (the right-hand side is cleaned on entry), so the
+  // operator's zero rows there and the identity rows of deal.II's operator give the same iterates.
+  struct Preconditioner
+  {
+    int      kind;
+    asm_ctx *ctx;
+    asm_mg * mg;
+  };
+
+  int
+  apply_preconditioner(const Preconditioner &pc, std::string &error, double *dst, const double *src)
+  {
+    int err = ASM_OK;
+    switch (pc.kind)
+      {
+        case ASM_SP_IDENTITY: err = asm_vec_copy(pc.ctx, dst, src); break;
+        case ASM_SP_INNER: err = asm_precond_vmult(pc.ctx, dst, src); break;
+        case ASM_SP_CHEBYSHEV: err = asm_cheb_vmult(pc.ctx, dst, src); break;
+        case ASM_SP_MULTIGRID:
+          err = asm_mg_vmult(pc.mg, dst, src);
+          if (err)
+            error = asm_mg_last_error(pc.mg);
+          return err;
+        default: error = "unknown system preconditioner"; return ASM_ERR_INVALID_VALUE;
+      }
+    if (err)
+      error = asm_last_error(pc.ctx);
+    return err;
+  }
+
+#define KS_CTX(expr)                       \
+  do                                       \
+    {                                      \
+      const int e_ = (expr);               \
+      if (e_ != ASM_OK)                    \
+        {                                  \
+          error = asm_last_error(ctx);     \
+          return e_;                       \
+        }                                  \
+    }                                      \
+  while (0)
+#define KS_TRY(expr)                       \
+  do                                       \
+    {                                      \
+      const int e_ = (expr);               \
+      if (e_ != ASM_OK)                    \
+        return e_;                         \
+    }                                      \
+  while (0)
+
+  struct WorkVectors
+  {
+    asm_ctx *             ctx;
+    std::vector<double *> v;
+    explicit WorkVectors(asm_ctx *c)
+      : ctx(c)
+    {}
+    ~WorkVectors()
+    {
+      for (double *p : v)
+        (void)asm_vector_free(ctx, p);
+    }
+    double *get()
+    {
+      double *p = nullptr;
+      if (asm_vector_alloc(ctx, &p) != ASM_OK)
+        return nullptr;
+      v.push_back(p);
+      return p;
+    }
+  };
+
+  // deal.II SolverCG: x_0 = 0, criterion on the unpreconditioned residual
+  int
+  solve_cg(asm_ctx *ctx, const Preconditioner &pc, const asm_solver_params &sp, double *x, const double *b, asm_solver_result &res,
+           std::string &error, double *const *work = nullptr)
+  {
+    WorkVectors w(ctx);
+    double *    r = work ? work[0] : w.get(), *z = work ? work[1] : w.get(), *p = work ? work[2] : w.get(),
+           *q = work ? work[3] : w.get();
+    if (!r || !z || !p || !q)
+      {
+        error = "solver: vector allocation failed";
+        return ASM_ERR_DEVICE;
+      }
+    KS_CTX(asm_vec_zero(ctx, x));
+    KS_CTX(asm_vec_copy(ctx, r, b));
+    double rr = 0., rz = 0., pq = 0.;
+    KS_CTX(asm_vec_dot(ctx, r, r, &rr));
+    res.initial_residual = res.final_residual = std::sqrt(rr);
+    const double tol     = std::max(sp.abs_tolerance, sp.rel_tolerance * res.initial_residual);
+    res.n_iterations     = 0;
+    res.converged        = res.initial_residual <= tol;
+    if (res.converged)
+      return ASM_OK;
+    KS_TRY(apply_preconditioner(pc, error, z, r));
+    KS_CTX(asm_vec_copy(ctx, p, z));
+    KS_CTX(asm_vec_dot(ctx, r, z, &rz));
+    for (int it = 1; it <= sp.max_iterations; ++it)
+      {
+        KS_CTX(asm_op_vmult(ctx, q, p));
+        KS_CTX(asm_vec_dot(ctx, p, q, &pq));
+        const double alpha = rz / pq;
+        KS_CTX(asm_vec_axpby(ctx, x, alpha, p, 1.));
+        KS_CTX(asm_vec_axpby(ctx, r, -alpha, q, 1.));
+        KS_CTX(asm_vec_dot(ctx, r, r, &rr));
+        res.n_iterations   = it;
+        res.final_residual = std::sqrt(rr);
+        if (res.final_residual <= tol)
+          {
+            res.converged = 1;
+            return ASM_OK;
+          }
+        KS_TRY(apply_preconditioner(pc, error, z, r));
+        double rz_new = 0.;
+        KS_CTX(asm_vec_dot(ctx, r, z, &rz_new));
+        KS_CTX(asm_vec_axpby(ctx, p, 1., z, rz_new / rz));
+        rz = rz_new;
+      }
+    return ASM_OK;
+  }
+
+  // deal.II SolverGMRES, classical Gram-Schmidt, restarted with max_n_tmp_vectors - 2 Krylov vectors
+  int
+  solve_gmres(asm_ctx *ctx, const Preconditioner &pc, const asm_solver_params &sp, double *x, const double *b, asm_solver_result &res,
+              std::string &error)
+  {
+    const int   m     = std::max(1, sp.max_n_tmp_vectors - 2);
+    const bool  right = sp.right_preconditioning != 0;
+    WorkVectors w(ctx);
+    std::vector<double *> V(m + 1);
+    for (auto &v : V)
+      v = w.get();
+    double *t = w.get(), *u = w.get();
+    if (!t || !u || !V.back())
+      {
+        error = "solver: vector allocation failed";
+        return ASM_ERR_DEVICE;
+      }
+    KS_CTX(asm_vec_zero(ctx, x));
+    double *r = V[0];
+    if (right)
+      KS_CTX(asm_vec_copy(ctx, r, b));
+    else
+      KS_TRY(apply_preconditioner(pc, error, r, b));
+    double beta2 = 0.;
+    KS_CTX(asm_vec_dot(ctx, r, r, &beta2));
+    double beta          = std::sqrt(beta2);
+    res.initial_residual = res.final_residual = beta;
+    const double tol     = std::max(sp.abs_tolerance, sp.rel_tolerance * beta);
+    res.n_iterations     = 0;
+    res.converged        = beta <= tol;
+    if (res.converged)
+      return ASM_OK;
+    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m);
+    int                 it = 0;
+    while (it < sp.max_iterations)
+      {
+        std::fill(H.begin(), H.end(), 0.);
+        std::fill(g.begin(), g.end(), 0.);
+        KS_CTX(asm_vec_scale(ctx, V[0], 1. / beta, V[0]));
+        g[0]       = beta;
+        int k_done = 0;
+        for (int k = 0; k < m; ++k)
+          {
+            // w = A M^-1 v_k (right) or M^-1 A v_k (left), into V[k+1]
+            if (right)
+              {
+                KS_TRY(apply_preconditioner(pc, error, t, V[k]));
+                KS_CTX(asm_op_vmult(ctx, V[k + 1], t));
+              }
+            else
+              {
+                KS_CTX(asm_op_vmult(ctx, t, V[k]));
+                KS_TRY(apply_preconditioner(pc, error, V[k + 1], t));
+              }
+            // classical Gram-Schmidt: all projections from the unmodified w
+            for (int i = 0; i <= k; ++i)
+              KS_CTX(asm_vec_dot(ctx, V[k + 1], V[i], &H[(size_t)i * m + k]));
+            for (int i = 0; i <= k; ++i)
+              KS_CTX(asm_vec_axpby(ctx, V[k + 1], -H[(size_t)i * m + k], V[i], 1.));
+            double nn = 0.;
+            KS_CTX(asm_vec_dot(ctx, V[k + 1], V[k + 1], &nn));
+            const double hk1 = std::sqrt(nn);
+            H[(size_t)(k + 1) * m + k] = hk1;
+            if (hk1 > 0.)
+              KS_CTX(asm_vec_scale(ctx, V[k + 1], 1. / hk1, V[k + 1]));
+            for (int i = 0; i < k; ++i)
+              {
+                const double a = H[(size_t)i * m + k], c = H[(size_t)(i + 1) * m + k];
+                H[(size_t)i * m + k]       = cs[i] * a + sn[i] * c;
+                H[(size_t)(i + 1) * m + k] = -sn[i] * a + cs[i] * c;
+              }
+            const double d = std::hypot(H[(size_t)k * m + k], H[(size_t)(k + 1) * m + k]);
+            cs[k]          = H[(size_t)k * m + k] / d;
+            sn[k]          = H[(size_t)(k + 1) * m + k] / d;
+            H[(size_t)k * m + k]       = d;
+            H[(size_t)(k + 1) * m + k] = 0.;
+            g[k + 1]                   = -sn[k] * g[k];
+            g[k]                       = cs[k] * g[k];
+            ++it;
+            k_done             = k + 1;
+            res.n_iterations   = it;
+            res.final_residual = std::fabs(g[k + 1]);
+            if (res.final_residual <= tol || it >= sp.max_iterations)
+              break;
+          }
+        // back substitution and update x += [M^-1] sum_i y_i v_i
+        for (int i = k_done - 1; i >= 0; --i)
+          {
+            double s = g[i];
+            for (int j = i + 1; j < k_done; ++j)
+              s -= H[(size_t)i * m + j] * y[j];
+            y[i] = s / H[(size_t)i * m + i];
+          }
+        KS_CTX(asm_vec_zero(ctx, u));
+        for (int i = 0; i < k_done; ++i)
+          KS_CTX(asm_vec_axpby(ctx, u, y[i], V[i], 1.));
+        if (right)
+          {
+            KS_TRY(apply_preconditioner(pc, error, t, u));
+            KS_CTX(asm_vec_axpby(ctx, x, 1., t, 1.));
+          }
+        else
+          KS_CTX(asm_vec_axpby(ctx, x, 1., u, 1.));
+        if (res.final_residual <= tol)
+          {
+            res.converged = 1;
+            return ASM_OK;
+          }
+        if (it >= sp.max_iterations)
+          return ASM_OK;
+        // restart from the true residual
+        KS_CTX(asm_op_vmult(ctx, t, x));
+        KS_CTX(asm_vec_copy(ctx, u, b));
+        KS_CTX(asm_vec_axpby(ctx, u, -1., t, 1.));
+        if (right)
+          KS_CTX(asm_vec_copy(ctx, V[0], u));
+        else
+          KS_TRY(apply_preconditioner(pc, error, V[0], u));
+        KS_CTX(asm_vec_dot(ctx, V[0], V[0], &beta2));
+        beta = std::sqrt(beta2);
+      }
+    return ASM_OK;
+  }
+
+  // ---- V-cycle (deal.II Multigrid::level_v_step) -----------------------------------------------------
+  int
+  v_cycle(asm_mg *mg, const int level)
+  {
+    Level &lv = mg->levels[level];
+    if (level == 0)
+      {
+        if (mg->mp.coarse_solver == ASM_MG_COARSE_SMOOTHER)
+          {
+            MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, lv.x, lv.b));
+            return ASM_OK;
+          }
+        // MGCoarseGridIterativeSolver-like: Jacobi-preconditioned CG (the level-0 context is a diagonal one)
+        asm_solver_params sp;
+        asm_solver_params_default(&sp);
+        sp.type           = ASM_SOLVER_CG;
+        sp.rel_tolerance  = mg->mp.coarse_rel_tolerance;
+        sp.abs_tolerance  = 0.;
+        sp.max_iterations = mg->mp.coarse_max_iterations;
+        asm_solver_result res;
+        double *const     work[4] = {lv.r, mg->cg_z, mg->cg_p, mg->cg_q};
+        return solve_cg(lv.ctx, Preconditioner{ASM_SP_INNER, lv.ctx, nullptr}, sp, lv.x, lv.b, res, mg->error, work);
+      }
+    Level &lc = mg->levels[level - 1];
+    MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, lv.x, lv.b));                                    // pre-smoothing, x_0 = 0
+    MG_CTX(mg, lv.ctx, asm_op_vmult_fused(lv.ctx, ASM_FUSED_RESIDUAL, lv.r, lv.x, lv.b));      // r = b - A x
+    MG_TRY(asm_mg_restrict(mg, level, lc.b, lv.r));
+    MG_TRY(v_cycle(mg, level - 1));
+    MG_TRY(asm_mg_prolongate_add(mg, level, lv.x, lc.x));
+    if (!mg->mp.one_sided_v_cycle)
+      MG_CTX(mg, lv.ctx, asm_cheb_step(lv.ctx, lv.x, lv.b));                                   // post-smoothing
+    return ASM_OK;
+  }
+} // namespace
+
+extern "C" {
+
+void
+asm_mg_params_default(asm_mg_params *p)
+{
+  std::memset(p, 0, sizeof(*p));
+  p->mg_type               = ASM_MG_H;      // "mg type", default "h"
+  p->p_sequence            = ASM_MG_BISECT; // "mg p sequence", default "bisect"
+  p->one_sided_v_cycle     = 0;
+  p->coarse_solver         = ASM_MG_COARSE_CG;
+  p->coarse_rel_tolerance  = 1e-3;
+  p->coarse_max_iterations = 200;
+  p->estimate_eigenvalues  = 1;
+}
+
+void
+asm_solver_params_default(asm_solver_params *p)
+{
+  p->type                  = ASM_SOLVER_GMRES;
+  p->max_iterations        = 1000;
+  p->abs_tolerance         = 1e-10;
+  p->rel_tolerance         = 1e-2;
+  p->right_preconditioning = 1;
+  p->max_n_tmp_vectors     = 30;
+}
+
+const char *
+asm_mg_last_error(const asm_mg *mg)
+{
+  return mg ? mg->error.c_str() : g_mg_create_error.c_str();
+}
+
+void
+asm_mg_destroy(asm_mg *mg)
+{
+  if (!mg)
+    return;
+  const DeviceGuard guard(mg->device);
+  (void)hipStreamSynchronize(mg->stream);
+  if (!mg->levels.empty() && mg->levels[0].ctx)
+    for (double *v : {mg->cg_p, mg->cg_z, mg->cg_q})
+      if (v)
+        (void)asm_vector_free(mg->levels[0].ctx, v);
+  for (Level &lv : mg->levels)
+    {
+      if (lv.ctx)
+        {
+          for (double *v : {lv.x, lv.b, lv.r})
+            if (v)
+              (void)asm_vector_free(lv.ctx, v);
+          asm_destroy(lv.ctx);
+        }
+      for (void *p : lv.allocs)
+        (void)hipFree(p);
+    }
+  delete mg;
+}
+
+int
+asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
+{
+  *out = nullptr;
+  asm_mg_params mp;
+  if (mp_in)
+    mp = *mp_in;
+  else
+    asm_mg_params_default(&mp);
+  if (fine->world_size != 1)
+    {
+      g_mg_create_error = "multigrid level hierarchies are built on one rank only (world_size must be 1)";
+      return ASM_ERR_NOT_SUPPORTED;
+    }
+  if (mp.mg_type < ASM_MG_H || mp.mg_type > ASM_MG_PH || mp.p_sequence < ASM_MG_BISECT || mp.p_sequence > ASM_MG_GO_TO_ONE)
+    {
+      g_mg_create_error = "Multigrid variant / p sequence is not known!";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  std::unique_ptr<asm_mg> holder(new asm_mg);
+  asm_mg *                mg = holder.get();
+  mg->mp                     = mp;
+  mg->stream                 = (hipStream_t)fine->stream;
+  const auto fail            = [&](const int code, const std::string &msg) {
+    g_mg_create_error = msg;
+    asm_mg_destroy(holder.release());
+    return code;
+  };
+  const std::vector<LevelSpec> specs = level_sequence(*fine, mp);
+  mg->levels.resize(specs.size());
+  for (size_t l = 0; l < specs.size(); ++l)
+    {
+      Level &lv = mg->levels[l];
+      lv.params = *fine;
+      for (int d = 0; d < 3; ++d)
+        lv.params.n_cells[d] = specs[l].nc[d];
+      lv.params.degree = specs[l].p;
+      lv.params.rank   = 0;
+      // the coarse CG solve is Jacobi-preconditioned; vertex-star patches need degree >= 2
+      if ((l == 0 && mp.coarse_solver == ASM_MG_COARSE_CG) || (lv.params.element_centric == 0 && specs[l].p < 2))
+        lv.params.precond_type = ASM_PRECOND_DIAGONAL;
+      if (l + 1 < specs.size())
+        lv.params.kernel_variant = ASM_KERNEL_AUTO; // a kernel family forced for the fine level need not exist on the others
+      if (lv.params.geometry == ASM_GEOM_Q2_POINTS)
+        return fail(ASM_ERR_NOT_SUPPORTED, "multigrid levels are generated for Cartesian and Kershaw geometry, not for caller-supplied points");
+      if (const int err = asm_create(&lv.params, &lv.ctx))
+        return fail(err, std::string("level ") + std::to_string(l) + ": " + asm_last_error(nullptr));
+      (void)asm_vector_layout(lv.ctx, &lv.layout);
+      if (asm_vector_alloc(lv.ctx, &lv.x) || asm_vector_alloc(lv.ctx, &lv.b) || asm_vector_alloc(lv.ctx, &lv.r))
+        return fail(ASM_ERR_DEVICE, "level vector allocation failed");
+    }
+  {
+    asm_ctx *c0 = mg->levels[0].ctx;
+    int      dev = 0;
+    (void)hipGetDevice(&dev);
+    mg->device = fine->device >= 0 ? fine->device : dev;
+    if (asm_vector_alloc(c0, &mg->cg_p) || asm_vector_alloc(c0, &mg->cg_z) || asm_vector_alloc(c0, &mg->cg_q))
+      return fail(ASM_ERR_DEVICE, "coarse solver vector allocation failed");
+  }
+  const DeviceGuard guard(mg->device);
+  for (size_t l = 1; l < specs.size(); ++l)
+    {
+      Level &lv = mg->levels[l];
+      for (int d = 0; d < 3; ++d)
+        {
+          std::string error;
+          if (!build_transfer_1d(lv, lv.params, mg->levels[l - 1].params, d, lv.transfer.d[d], error))
+            return fail(ASM_ERR_NOT_SUPPORTED, error);
+        }
+      lv.transfer.fine   = box_of(lv.layout);
+      lv.transfer.coarse = box_of(mg->levels[l - 1].layout);
+    }
+  if (mp.estimate_eigenvalues)
+    for (size_t l = 0; l < specs.size(); ++l)
+      {
+        if (l == 0 && mp.coarse_solver != ASM_MG_COARSE_SMOOTHER)
+          continue;
+        double lam = 0.;
+        if (const int err = asm_cheb_estimate_eigenvalues(mg->levels[l].ctx, &lam))
+          return fail(err, std::string("eigenvalue estimate on level ") + std::to_string(l) + ": " + asm_last_error(mg->levels[l].ctx));
+      }
+  *out = holder.release();
+  return ASM_OK;
+}
+
+int
+asm_mg_n_levels(const asm_mg *mg, int32_t *n_levels)
+{
+  *n_levels = (int32_t)mg->levels.size();
+  return ASM_OK;
+}
+
+int
+asm_mg_level_context(asm_mg *mg, int32_t level, asm_ctx **ctx)
+{
+  if (level < 0 || level >= (int32_t)mg->levels.size())
+    {
+      mg->error = "asm_mg_level_context: no such level";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  *ctx = mg->levels[level].ctx;
+  return ASM_OK;
+}
+
+int
+asm_mg_prolongate_add(asm_mg *mg, int32_t level, double *dst_fine, const double *src_coarse)
+{
+  if (level < 1 || level >= (int32_t)mg->levels.size())
+    {
+      mg->error = "asm_mg_prolongate_add: level must be in [1, n_levels)";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  const DeviceGuard   guard(mg->device);
+  const TransferArgs &t = mg->levels[level].transfer;
+  const long long     n = (long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2];
+  hipLaunchKernelGGL(prolongate_add_kernel, dim3(launch_blocks(n)), dim3(256), 0, mg->stream, t, dst_fine, src_coarse);
+  return check_launch(mg, "prolongate_add");
+}
+
+int
+asm_mg_restrict(asm_mg *mg, int32_t level, double *dst_coarse, const double *src_fine)
+{
+  if (level < 1 || level >= (int32_t)mg->levels.size())
+    {
+      mg->error = "asm_mg_restrict: level must be in [1, n_levels)";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  const DeviceGuard   guard(mg->device);
+  const TransferArgs &t = mg->levels[level].transfer;
+  const long long     n = (long long)t.coarse.size[0] * t.coarse.size[1] * t.coarse.size[2];
+  hipLaunchKernelGGL(restrict_kernel, dim3(launch_blocks(n)), dim3(256), 0, mg->stream, t, dst_coarse, src_fine);
+  return check_launch(mg, "restrict");
+}
+
+int
+asm_mg_vmult(asm_mg *mg, double *dst, const double *src)
+{
+  const DeviceGuard guard(mg->device);
+  Level &           top = mg->levels.back();
+  MG_CTX(mg, top.ctx, asm_vec_copy(top.ctx, top.b, src));
+  MG_TRY(v_cycle(mg, (int)mg->levels.size() - 1));
+  MG_CTX(mg, top.ctx, asm_vec_copy(top.ctx, dst, top.x));
+  return ASM_OK;
+}
+
+int
+asm_solve(asm_ctx *ctx, asm_mg *mg, int preconditioner, const asm_solver_params *sp_in, double *x, const double *b,
+          asm_solver_result *result)
+{
+  asm_solver_params sp;
+  if (sp_in)
+    sp = *sp_in;
+  else
+    asm_solver_params_default(&sp);
+  std::string  local_error;
+  std::string &error = mg ? mg->error : local_error;
+  if (preconditioner == ASM_SP_MULTIGRID)
+    {
+      if (mg == nullptr)
+        return ASM_ERR_INVALID_VALUE;
+      asm_ctx *fine = mg->levels.back().ctx;
+      if (ctx != nullptr && ctx != fine)
+        {
+          error = "asm_solve: with ASM_SP_MULTIGRID the context must be the finest level of the multigrid object";
+          return ASM_ERR_INVALID_VALUE;
+        }
+      ctx = fine;
+    }
+  if (ctx == nullptr || result == nullptr || x == nullptr || b == nullptr || x == b)
+    return ASM_ERR_INVALID_VALUE;
+  std::memset(result, 0, sizeof(*result));
+  const Preconditioner pc{preconditioner, ctx, mg};
+  // the right-hand side with zeros on constrained DoFs (AffineConstraints::set_zero, as op.rhs() leaves it)
+  WorkVectors w(ctx);
+  double *    rhs = w.get();
+  if (rhs == nullptr || asm_vec_copy(ctx, rhs, b) || asm_vec_constraints_set_zero(ctx, rhs))
+    {
+      error = asm_last_error(ctx);
+      return ASM_ERR_DEVICE;
+    }
+  if (sp.type == ASM_SOLVER_CG)
+    return solve_cg(ctx, pc, sp, x, rhs, *result, error);
+  if (sp.type == ASM_SOLVER_GMRES)
+    return solve_gmres(ctx, pc, sp, x, rhs, *result, error);
+  error = "Solver <" + std::to_string(sp.type) + "> is not known!";
+  return ASM_ERR_INVALID_VALUE;
+}
+} // extern "C"

@@ -256,6 +256,18 @@ int asm_update_ghost_values(asm_ctx *ctx, double *v);
  * (include/matrix_free_internal.h:49-103) */
 int asm_compress_add(asm_ctx *ctx, double *v);
 
+/* LinearAlgebra::distributed::Vector operations the reference's Krylov solvers and multigrid call on
+ * its vectors (deal.II SolverCG / SolverGMRES / Multigrid: operator*, add, sadd, equ, operator=):
+ * all on the context's stream; elementwise ones cover the whole allocation (ghost planes included,
+ * which keeps ghost values consistent), the inner product runs over the owned DoFs and is summed
+ * over all ranks (synchronous: the value is returned to the host). */
+int asm_vec_dot(asm_ctx *ctx, const double *x, const double *y, double *result); /* x * y */
+int asm_vec_axpby(asm_ctx *ctx, double *y, double a, const double *x, double b); /* y = a x + b y (sadd) */
+int asm_vec_scale(asm_ctx *ctx, double *y, double a, const double *x);           /* y = a x (equ); y may be x */
+int asm_vec_copy(asm_ctx *ctx, double *y, const double *x);                      /* y = x */
+int asm_vec_zero(asm_ctx *ctx, double *y);                                       /* y = 0 */
+int asm_vec_constraints_set_zero(asm_ctx *ctx, double *y); /* AffineConstraints::set_zero: y = 0 on Dirichlet DoFs */
+
 /* ----- operators -------------------------------------------------------- */
 
 /* LaplaceOperatorMatrixFree::vmult(dst, src), include/operator.h:1353-1365 */
@@ -326,6 +338,101 @@ int asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_m
 int asm_set_keep_ghosts(asm_ctx *ctx, int on);
 
 int asm_time_calls(asm_ctx *ctx, int what, int reps, double *dst, const double *src, float *ms);
+
+/* ----- the smoother's callers: multigrid V-cycle, transfers, outer Krylov solvers ----------------------
+ * (single rank: level hierarchies are not block-decomposed yet, world_size > 1 is refused) */
+
+typedef struct asm_mg asm_mg;
+
+/* "mg type", element_centered_preconditioners_01.cc:552-553, 640-672 */
+enum asm_mg_type
+{
+  ASM_MG_H  = 0, /* geometric coarsening at the fine degree (default) */
+  ASM_MG_P  = 1, /* polynomial coarsening on the fine mesh */
+  ASM_MG_HP = 2, /* p levels on the coarsest mesh below the h levels */
+  ASM_MG_PH = 3  /* h levels at the lowest degree below the p levels (the experiments' choice) */
+};
+/* "mg p sequence", element_centered_preconditioners_01.cc:555-586 */
+enum asm_mg_p_sequence
+{
+  ASM_MG_BISECT          = 0,
+  ASM_MG_DECREASE_BY_ONE = 1,
+  ASM_MG_GO_TO_ONE       = 2
+};
+/* "mg coarse grid solver": the reference hands any system preconditioner to MGCoarseGridApplyPreconditioner
+ * (include/multigrid.h:264-265, 352-358; Trilinos ML AMG in the experiments, precondition.templates.h:592-613) */
+enum asm_mg_coarse
+{
+  ASM_MG_COARSE_SMOOTHER = 0, /* the level-0 Chebyshev smoother's vmult (tests/.../small fixtures) */
+  ASM_MG_COARSE_CG       = 1  /* Jacobi-preconditioned CG to a relative tolerance (in place of AMG) */
+};
+
+typedef struct asm_mg_params
+{
+  int32_t mg_type;           /* asm_mg_type */
+  int32_t p_sequence;        /* asm_mg_p_sequence */
+  int32_t one_sided_v_cycle; /* "one-sided v-cycle": identity post-smoother (include/multigrid.h:305-322) */
+  int32_t coarse_solver;     /* asm_mg_coarse */
+  double  coarse_rel_tolerance;   /* ASM_MG_COARSE_CG */
+  int32_t coarse_max_iterations;
+  int32_t estimate_eigenvalues; /* 1: run asm_cheb_estimate_eigenvalues on every level at creation */
+} asm_mg_params;
+
+void asm_mg_params_default(asm_mg_params *p);
+/* Level hierarchy of `fine` (cells, degree, smoother configuration; rank 0 of 1): level operators and
+ * smoothers are contexts of this library ("mg smoother" = the smoother `fine` describes, on every level with
+ * n_overlap clamped to the level's degree; vertex-star patches become the diagonal smoother at degree 1),
+ * MGTwoLevelTransfer between neighbouring levels (include/multigrid.h:289-299, 336-346). */
+int  asm_mg_create(const asm_params *fine, const asm_mg_params *mp, asm_mg **out);
+void asm_mg_destroy(asm_mg *mg);
+const char *asm_mg_last_error(const asm_mg *mg);
+int asm_mg_n_levels(const asm_mg *mg, int32_t *n_levels);
+/* level 0 = coarsest; the context of level n_levels-1 is the fine operator the outer solver works on */
+int asm_mg_level_context(asm_mg *mg, int32_t level, asm_ctx **ctx);
+/* MGTwoLevelTransfer between level (fine) and level-1 (coarse):
+ *   prolongate_and_add: dst_fine += P src_coarse;  restrict_and_add into a zeroed vector: dst_coarse = P^T src_fine
+ * (constrained DoFs of either level neither receive nor contribute) */
+int asm_mg_prolongate_add(asm_mg *mg, int32_t level, double *dst_fine, const double *src_coarse);
+int asm_mg_restrict(asm_mg *mg, int32_t level, double *dst_coarse, const double *src_fine);
+/* PreconditionMG::vmult (include/multigrid.h:466-472): one V-cycle from a zero initial guess; dst, src: vectors of
+ * the finest level.  Pre-smoothing = smoother vmult, post-smoothing = smoother step (deal.II MGSmootherRelaxation) */
+int asm_mg_vmult(asm_mg *mg, double *dst, const double *src);
+
+/* solve(), element_centered_preconditioners_01.cc:108-263: SolverCG / SolverGMRES under ReductionControl */
+enum asm_solver_type
+{
+  ASM_SOLVER_CG    = 0,
+  ASM_SOLVER_GMRES = 1
+};
+/* create_system_preconditioner, include/precondition.templates.h:249-620 (the types this path covers) */
+enum asm_system_preconditioner
+{
+  ASM_SP_IDENTITY  = 0,
+  ASM_SP_INNER     = 1, /* the context's FDM / Diagonal preconditioner */
+  ASM_SP_CHEBYSHEV = 2, /* the context's Chebyshev smoother (vmult) */
+  ASM_SP_MULTIGRID = 3  /* one V-cycle of the asm_mg given to asm_solve */
+};
+typedef struct asm_solver_params
+{
+  int32_t type;                  /* "type": CG | GMRES */
+  int32_t max_iterations;        /* "max iterations", 1000 */
+  double  abs_tolerance;         /* "abs tolerance", 1e-10 */
+  double  rel_tolerance;         /* "rel tolerance", 1e-2 */
+  int32_t right_preconditioning; /* "use right preconditioning", true */
+  int32_t max_n_tmp_vectors;     /* "max n tmp vectors", 30 (Krylov vectors per restart = this - 2) */
+} asm_solver_params;
+typedef struct asm_solver_result
+{
+  int32_t n_iterations; /* SolverControl::last_step() */
+  int32_t converged;
+  double  initial_residual, final_residual;
+} asm_solver_result;
+void asm_solver_params_default(asm_solver_params *p);
+/* x = 0 initially (as solve() sets it); ctx: the fine-level context (for ASM_SP_MULTIGRID: level n_levels-1 of mg,
+ * ctx may then be NULL); classical Gram-Schmidt in GMRES, the residual estimate of the Givens recurrence
+ * decides convergence, as in deal.II */
+int asm_solve(asm_ctx *ctx, asm_mg *mg, int preconditioner, const asm_solver_params *sp, double *x, const double *b,
+              asm_solver_result *result);
 
 /* ----- testing aids ---------------------------------------------------------
  * All ranks of a partition as contexts of ONE process on ONE device: RCCL cannot

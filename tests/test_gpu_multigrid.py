@@ -1,0 +1,183 @@
+"""GPU parity of the smoother's callers (transfers, V-cycle, coarse solver, outer Krylov solvers)
+against the oracle twin oracle/asm_oracle_mg.py, which tests/test_oracle_mg_golden.py pins on the reference's own
+iteration-count fixtures.  Everything goes through the C ABI (asm_mg_*, asm_solve)."""
+import numpy as np
+import pytest
+
+import asm_oracle as orc
+import asm_oracle_mg as omg
+from test_gpu_parity import BCMAP, TOL, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def fine_params(pkg, nc, p, bc, geometry="cartesian", **kw):
+    return pkg.make_params(degree=p, n_cells=nc, boundary=[bc] * 3 if isinstance(bc, str) else list(bc), geometry=geometry,
+                           kershaw_eps=(0.3, 0.3), **kw)
+
+
+def oracle_hierarchy(nc, p, bc, mg_type, weighting, n_overlap, degree, lams, geometry="cartesian", coarse="smoother",
+                     coarse_rel_tol=1e-3, one_sided=False, p_sequence="bisect", polynomial_type="1st kind"):
+    bcs = [BCMAP[b] for b in ([bc] * 3 if isinstance(bc, str) else bc)]
+    mapfn = (lambda pts: orc.kershaw(0.3, 0.3, pts)) if geometry == "kershaw" else None
+
+    def smoother(level, mesh, op):
+        prec = orc.ASPoissonPreconditioner(mesh, n_overlap, weighting)
+        return orc.Chebyshev(op, prec, degree=degree, lambda_max=None if lams is None else lams[level], polynomial_type=polynomial_type)
+
+    def coarse_factory(mesh, op):
+        if coarse == "smoother":
+            return smoother(0, mesh, op)
+        return omg.CoarseCG(op, rel_tol=coarse_rel_tol)
+
+    return omg.build_multigrid(nc, p, bcs, smoother, coarse_factory, mg_type=mg_type, p_sequence=p_sequence, mapfn=mapfn,
+                               one_sided=one_sided)
+
+
+@pytest.mark.parametrize(
+    "nc,p,bc,mg_type,p_sequence",
+    [
+        ((4, 2, 2), 4, "dirichlet", "p", "bisect"),
+        ((4, 2, 2), 7, ["dirichlet", "neumann", "dirichlet"], "p", "bisect"),
+        ((2, 2, 2), 5, "neumann", "p", "decrease by one"),
+        ((8, 4, 4), 1, "dirichlet", "h", "bisect"),
+        ((4, 4, 2), 3, ["neumann", "dirichlet", "dirichlet"], "h", "bisect"),
+        ((4, 4, 4), 4, "dirichlet", "ph", "bisect"),
+    ],
+)
+def test_transfer_parity(pkg, nc, p, bc, mg_type, p_sequence):
+    """prolongate_and_add / restrict_and_add of every level pair against the oracle's Kronecker-product transfer"""
+    with pkg.Multigrid(fine_params(pkg, nc, p, bc), mg_type=mg_type, p_sequence=p_sequence, estimate_eigenvalues=False) as mg:
+        seq = omg.level_sequence(nc, p, mg_type, p_sequence)
+        assert mg.n_levels == len(seq)
+        bcs = [BCMAP[b] for b in ([bc] * 3 if isinstance(bc, str) else bc)]
+        meshes = [orc.Mesh(cells, deg, bcs) for cells, deg in seq]
+        rng = np.random.default_rng(5)
+        for l in range(1, mg.n_levels):
+            T = omg.Transfer(meshes[l], meshes[l - 1])
+            cf, cc = mg.levels[l], mg.levels[l - 1]
+            assert cf.n_dofs == meshes[l].n_dofs and cc.n_dofs == meshes[l - 1].n_dofs
+            xc, xf = rng.uniform(-1, 1, meshes[l - 1].n_dofs), rng.uniform(-1, 1, meshes[l].n_dofs)
+            vc, vf = cc.vector(xc), cf.vector(xf)
+            mg.prolongate_add(l, vf, vc)
+            assert rel(vf.get(), xf + T.prolongate(xc)) < TOL
+            rf = rng.uniform(-1, 1, meshes[l].n_dofs)
+            wf, wc = cf.vector(rf), cc.vector(np.full(meshes[l - 1].n_dofs, 7.0))
+            mg.restrict(l, wc, wf)
+            assert rel(wc.get(), T.restrict(rf)) < TOL
+            for v in (vc, vf, wf, wc):
+                v.free()
+
+
+@pytest.mark.parametrize(
+    "nc,p,bc,geometry,mg_type,weighting,degree,one_sided,poly",
+    [
+        ((4, 4, 4), 4, "dirichlet", "cartesian", "ph", "post", 2, False, "1st kind"),
+        ((8, 4, 4), 4, "dirichlet", "cartesian", "ph", "symm", 1, True, "1st kind"),
+        ((4, 4, 4), 3, "dirichlet", "cartesian", "h", "post", 3, False, "4th kind"),
+        ((6, 2, 2), 4, "dirichlet", "kershaw", "p", "post", 2, False, "1st kind"),
+    ],
+)
+def test_v_cycle_parity(pkg, nc, p, bc, geometry, mg_type, weighting, degree, one_sided, poly):
+    """PreconditionMG::vmult: one V-cycle with Chebyshev + FDM smoothing on every level, coarse level = its smoother;
+    the same eigenvalue bounds on both sides"""
+    prm = fine_params(pkg, nc, p, bc, geometry, weighting=weighting, cheb_degree=degree, polynomial_type=poly)
+    with pkg.Multigrid(prm, mg_type=mg_type, coarse="smoother", one_sided=one_sided, estimate_eigenvalues=False) as mg:
+        lams = [1.3 + 0.1 * l for l in range(mg.n_levels)]
+        for l, c in enumerate(mg.levels):
+            c.set_eigenvalue(lams[l])
+        M, meshes, ops = oracle_hierarchy(nc, p, bc, mg_type, weighting, 1, degree, lams, geometry, one_sided=one_sided,
+                                          polynomial_type=poly)
+        b = np.random.default_rng(9).uniform(-1, 1, meshes[-1].n_dofs)
+        b[meshes[-1].constrained_mask()] = 0.0
+        bv, xv = mg.fine.vector(b), mg.fine.vector()
+        mg.vmult(xv, bv)
+        assert rel(xv.get(), M.vmult(b)) < 10 * TOL  # several sweeps deep: a few ulps more than one sweep
+        bv.free()
+        xv.free()
+
+
+@pytest.mark.parametrize(
+    "nc,p,bc,geometry,mg_type,solver,weighting,degree,rel_tol",
+    [
+        ((4, 4, 4), 4, "dirichlet", "cartesian", "ph", "GMRES", "post", 1, 1e-5),
+        ((8, 4, 4), 4, "dirichlet", "cartesian", "ph", "CG", "symm", 2, 1e-6),
+        ((4, 4, 4), 3, "dirichlet", "cartesian", "h", "GMRES", "post", 3, 1e-8),
+        ((6, 4, 2), 4, "dirichlet", "kershaw", "p", "GMRES", "post", 2, 1e-5),
+    ],
+)
+def test_multigrid_preconditioned_solve(pkg, nc, p, bc, geometry, mg_type, solver, weighting, degree, rel_tol):
+    """solve() with the V-cycle as preconditioner and a CG coarse solve: iteration counts of the oracle twin, converged
+    solution; both sides estimate their own eigenvalues (same algorithm, same start vector)"""
+    prm = fine_params(pkg, nc, p, bc, geometry, weighting=weighting, cheb_degree=degree)
+    with pkg.Multigrid(prm, mg_type=mg_type, coarse="cg", coarse_rel_tol=1e-4) as mg:
+        M, meshes, ops = oracle_hierarchy(nc, p, bc, mg_type, weighting, 1, degree, None, geometry, coarse="cg", coarse_rel_tol=1e-4)
+        for l in range(1, mg.n_levels):
+            lam = mg.levels[l].cheb_parameters()["lambda_max"]
+            assert abs(lam - M.smoothers[l].lambda_hat) < 1e-8 * lam
+        mesh, op = meshes[-1], ops[-1]
+        b = np.random.default_rng(2).uniform(0, 1, mesh.n_dofs)
+        b[mesh.constrained_mask()] = 0.0
+        fn = omg.solve_gmres if solver == "GMRES" else omg.solve_cg
+        x_ref, it_ref = fn(op, b, M, rel_tol=rel_tol, abs_tol=0.0)
+        bv, xv = mg.fine.vector(b), mg.fine.vector()
+        res = mg.fine.solve(xv, bv, solver=solver, preconditioner="Multigrid", mg=mg, rel_tol=rel_tol, abs_tol=0.0)
+        assert res.converged == 1 and res.n_iterations == it_ref, (res.n_iterations, it_ref)
+        x = xv.get()
+        # The coarse CG makes the V-cycle a (slightly) non-linear preconditioner, so the residual estimate GMRES stops
+        # on may differ from the true residual: the true residual is compared with the oracle twin's, which has the
+        # same property, and agreement of the solutions is to solver accuracy, not to rounding.
+        true_res = np.linalg.norm(b - op.vmult(x, unit_constrained=True))
+        ref_res = np.linalg.norm(b - op.vmult(x_ref, unit_constrained=True))
+        assert true_res <= 1.05 * ref_res + 1e-12 * np.linalg.norm(b)
+        assert res.final_residual <= rel_tol * res.initial_residual
+        assert rel(x, x_ref) < 1e-6
+        bv.free()
+        xv.free()
+
+
+@pytest.mark.parametrize("solver", ["GMRES", "CG"])
+@pytest.mark.parametrize("precond", ["Identity", "inner", "Chebyshev"])
+def test_single_level_solvers(pkg, solver, precond):
+    """the fixtures' other system preconditioners (Identity, FDM / Diagonal, Chebyshev) under both solvers, 3-D"""
+    nc, p = (4, 3, 3), 3
+    weighting = "symm"  # symmetric preconditioner: valid for CG too
+    with pkg.Context(degree=p, n_cells=nc, boundary="dirichlet", weighting=weighting, cheb_degree=3, eig_n_iterations=20) as ctx:
+        mesh = orc.Mesh(nc, p, [orc.DIRICHLET] * 3)
+        op = orc.LaplaceOperator(mesh)
+        fdm = orc.ASPoissonPreconditioner(mesh, 1, weighting)
+        prec = {"Identity": omg.Identity(), "inner": fdm, "Chebyshev": orc.Chebyshev(op, fdm, degree=3, eig_n_iterations=20)}[precond]
+        if precond == "Chebyshev":
+            lam = ctx.estimate_eigenvalues()
+            assert abs(lam - prec.lambda_hat) < 1e-9 * lam
+        b = omg.right_hand_side_one(mesh)
+        fn = omg.solve_gmres if solver == "GMRES" else omg.solve_cg
+        x_ref, it_ref = fn(op, b, prec, rel_tol=1e-6, abs_tol=0.0)
+        bv, xv = ctx.vector(b), ctx.vector(np.ones(mesh.n_dofs))  # x is reset to zero by the solver
+        res = ctx.solve(xv, bv, solver=solver, preconditioner=precond, rel_tol=1e-6, abs_tol=0.0)
+        assert res.converged == 1 and res.n_iterations == it_ref, (res.n_iterations, it_ref)
+        assert rel(xv.get(), x_ref) < 1e-9
+        assert abs(res.initial_residual - np.linalg.norm(b)) < 1e-12 * np.linalg.norm(b)
+
+
+def test_gmres_restart_and_left_preconditioning(pkg):
+    nc, p = (4, 4, 2), 2
+    with pkg.Context(degree=p, n_cells=nc, boundary="dirichlet", precond="Diagonal", cheb_degree=1) as ctx:
+        mesh = orc.Mesh(nc, p, [orc.DIRICHLET] * 3)
+        op = orc.LaplaceOperator(mesh)
+        jac = orc.JacobiPreconditioner(op)
+        b = omg.right_hand_side_one(mesh)
+        bv, xv = ctx.vector(b), ctx.vector()
+        for right, tmp in [(True, 7), (False, 7), (False, 30)]:
+            x_ref, it_ref = omg.solve_gmres(op, b, jac, rel_tol=1e-8, abs_tol=0.0, restart=tmp - 2, right=right)
+            res = ctx.solve(xv, bv, solver="GMRES", preconditioner="inner", rel_tol=1e-8, abs_tol=0.0, right_preconditioning=right,
+                            max_n_tmp_vectors=tmp)
+            assert res.n_iterations == it_ref, (right, tmp, res.n_iterations, it_ref)
+            assert rel(xv.get(), x_ref) < 1e-8
+
+
+def test_multigrid_refuses_what_it_does_not_cover(pkg):
+    with pytest.raises(RuntimeError, match="non-periodic"):
+        pkg.Multigrid(fine_params(pkg, (4, 4, 4), 4, "periodic"), mg_type="p")
+    with pytest.raises(RuntimeError, match="one rank"):
+        pkg.Multigrid(pkg.make_params(degree=2, n_cells=(4, 4, 4), world_size=2, rank=0))
