@@ -508,9 +508,14 @@ namespace
       }
     if (dst == ctx->exchanged_vec)
       ctx->exchanged_vec = nullptr;
-    HIP_TRY(hipMemsetAsync(dst, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+    // one rank: the residual is accumulated straight into a copy of b (no zeroing pass, no separate b - A x pass)
+    const bool fused_residual = mode == OP_RESIDUAL && !multi_rank(ctx);
+    if (fused_residual)
+      HIP_TRY(hipMemcpyAsync(dst, b, ctx->s.n_alloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    else
+      HIP_TRY(hipMemsetAsync(dst, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     prof_mark(ctx, 0, true);
-    const bool ok = laplace_generic(ctx->g, ctx->op, src, dst, false, ctx->stream);
+    const bool ok = laplace_generic(ctx->g, ctx->op, src, dst, false, ctx->stream, fused_residual ? -1.0 : 1.0);
     prof_mark(ctx, 0, false);
     if (!ok)
       {
@@ -522,7 +527,8 @@ namespace
       return err;
     if (mode == OP_RESIDUAL)
       {
-        vec_residual(dst, b, ctx->s.n_alloc, ctx->stream);
+        if (!fused_residual)
+          vec_residual(dst, b, ctx->s.n_alloc, ctx->stream);
         vec_constrained(ctx->g, 2, dst, src, b, ctx->stream); // r_c = b_c - x_c
       }
     return ASM_OK;

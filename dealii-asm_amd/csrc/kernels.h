@@ -13,7 +13,8 @@ namespace asmamd
   // otherwise tmp holds n_cells * m^3 doubles: patch results are stored there and summed per DoF
   // by a second kernel that writes every stored entry of dst (no zeroing, no atomics)
   bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, hipStream_t st);
-  bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st);
+  // dst += sign * A src (sign = -1 on a dst initialised with b gives the residual b - A src in one pass)
+  bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st, double sign = 1.0);
 
   // ---- tiled owner-computes sweeps (kernels_tiled.hip), degree 4, n_overlap 1
   enum TiledMode

@@ -762,7 +762,10 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
       lv.params.rank   = 0;
       // the coarse CG solve is Jacobi-preconditioned; vertex-star patches need degree >= 2
       if ((l == 0 && mp.coarse_solver == ASM_MG_COARSE_CG) || (lv.params.element_centric == 0 && specs[l].p < 2))
-        lv.params.precond_type = ASM_PRECOND_DIAGONAL;
+        {
+          lv.params.precond_type    = ASM_PRECOND_DIAGONAL;
+          lv.params.element_centric = 1; // (no patches are built for the diagonal smoother)
+        }
       if (l + 1 < specs.size())
         lv.params.kernel_variant = ASM_KERNEL_AUTO; // a kernel family forced for the fine level need not exist on the others
       if (lv.params.geometry == ASM_GEOM_Q2_POINTS)
