@@ -582,13 +582,33 @@ namespace
           }
         return ASM_OK;
       }
-    double *t = (mode == PC_PLAIN) ? dst : ctx->T;
     if (dst == ctx->exchanged_vec)
       ctx->exchanged_vec = nullptr;
+    FdmFused fu;
+    if (ctx->patch_tmp != nullptr && !multi_rank(ctx))
+      {
+        // one rank: the kernel that sums the patch results per DoF applies the vector update as well
+        // (no zeroing, no atomics, no separate update passes)
+        fu.mode  = mode;
+        fu.x     = x;
+        fu.x_old = x_old;
+        fu.f1    = f1;
+        fu.f2    = f2;
+        prof_mark(ctx, 1, true);
+        const bool ok = fdm_generic(ctx->g, ctx->f, src, dst, ctx->patch_tmp, fu, ctx->stream);
+        prof_mark(ctx, 1, false);
+        if (!ok)
+          {
+            ctx->error = "generic FDM kernel not available for this patch size";
+            return ASM_ERR_NOT_SUPPORTED;
+          }
+        return ASM_OK;
+      }
+    double *t = (mode == PC_PLAIN) ? dst : ctx->T;
     if (ctx->patch_tmp == nullptr)
       HIP_TRY(hipMemsetAsync(t, 0, n * sizeof(double), ctx->stream));
     prof_mark(ctx, 1, true);
-    const bool ok = fdm_generic(ctx->g, ctx->f, src, t, ctx->patch_tmp, ctx->stream);
+    const bool ok = fdm_generic(ctx->g, ctx->f, src, t, ctx->patch_tmp, fu, ctx->stream);
     prof_mark(ctx, 1, false);
     if (!ok)
       {

@@ -12,7 +12,14 @@ namespace asmamd
   // tmp == nullptr: contributions are added to dst with atomics (dst zeroed by the caller);
   // otherwise tmp holds n_cells * m^3 doubles: patch results are stored there and summed per DoF
   // by a second kernel that writes every stored entry of dst (no zeroing, no atomics)
-  bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, hipStream_t st);
+  // fu (with tmp only): the fused vector update applied by the summing kernel, TiledMode PC_* (declared below)
+  struct FdmFused
+  {
+    int           mode = 2; // PC_PLAIN
+    const double *x = nullptr, *x_old = nullptr;
+    double        f1 = 0., f2 = 1.;
+  };
+  bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, const FdmFused &fu, hipStream_t st);
   // dst += sign * A src (sign = -1 on a dst initialised with b gives the residual b - A src in one pass)
   bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st, double sign = 1.0);
 

@@ -383,8 +383,11 @@ namespace asmamd
         }
     }
 
+    // fu: the vector update PreconditionChebyshev hands over as post-operation (TiledMode PC_*), applied while the
+    // sum is stored (one rank only: with several ranks compress(add) comes between the sum and the update)
     __global__ void __launch_bounds__(BLOCK)
-    fdm_gather_kernel(const DevGrid g, const DevFdm f, const double *__restrict__ tmp, double *__restrict__ dst)
+    fdm_gather_kernel(const DevGrid g, const DevFdm f, const FdmFused fu, const double *__restrict__ src, const double *__restrict__ tmp,
+                      double *__restrict__ dst)
     {
       const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1, sz = g.ext_hi[2] - g.ext_lo[2] + 1;
       const long long n  = (long long)sx * sy * sz;
@@ -405,7 +408,22 @@ namespace asmamd
                   const long long cell = cx.cell[kx] + (long long)g.nc[0] * (cy.cell[ky] + (long long)g.nc[1] * cz.cell[kz]);
                   sum += tmp[cell * m3 + cz.idx[kz] * m2 + cy.idx[ky] * m + cx.idx[kx]];
                 }
-          dst[si * g.stride[0] + sj * g.stride[1] + sk * g.stride[2]] = sum;
+          const long long off = si * g.stride[0] + sj * g.stride[1] + sk * g.stride[2];
+          if (fu.mode != PC_PLAIN)
+            {
+              if (g.dirichlet(0, si + g.ext_lo[0]) || g.dirichlet(1, sj + g.ext_lo[1]) || g.dirichlet(2, sk + g.ext_lo[2]))
+                sum = src[off]; // unit rows on constrained DoFs (include/matrix_free_internal.h:247-255)
+              if (fu.mode == PC_FIRST)
+                sum = fu.f2 * sum;
+              else if (fu.mode == PC_STEP1)
+                sum = fu.f1 * fu.x[off] + fu.f2 * sum;
+              else
+                {
+                  const double xv = fu.x[off];
+                  sum             = xv + fu.f1 * (xv - fu.x_old[off]) + fu.f2 * sum;
+                }
+            }
+          dst[off] = sum;
         }
     }
 
@@ -797,7 +815,7 @@ namespace asmamd
   // -----------------------------------------------------------------------
   template <int M>
   static void
-  launch_fdm(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, hipStream_t st)
+  launch_fdm(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, const FdmFused &fu, hipStream_t st)
   {
     const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
     const int blocks = (ncells + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
@@ -809,26 +827,26 @@ namespace asmamd
     hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, tmp);
     const long long n = (long long)(g.ext_hi[0] - g.ext_lo[0] + 1) * (g.ext_hi[1] - g.ext_lo[1] + 1) * (g.ext_hi[2] - g.ext_lo[2] + 1);
     const long long gb = std::min<long long>((n + BLOCK - 1) / BLOCK, 1 << 20);
-    hipLaunchKernelGGL(fdm_gather_kernel, dim3((unsigned)gb), dim3(BLOCK), 0, st, g, f, tmp, dst);
+    hipLaunchKernelGGL(fdm_gather_kernel, dim3((unsigned)gb), dim3(BLOCK), 0, st, g, f, fu, src, tmp, dst);
   }
 
   bool
-  fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, hipStream_t st)
+  fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, const FdmFused &fu, hipStream_t st)
   {
     switch (f.m)
       {
-        case 2: launch_fdm<2>(g, f, src, dst, tmp, st); break;
-        case 3: launch_fdm<3>(g, f, src, dst, tmp, st); break;
-        case 4: launch_fdm<4>(g, f, src, dst, tmp, st); break;
-        case 5: launch_fdm<5>(g, f, src, dst, tmp, st); break;
-        case 6: launch_fdm<6>(g, f, src, dst, tmp, st); break;
-        case 7: launch_fdm<7>(g, f, src, dst, tmp, st); break;
-        case 8: launch_fdm<8>(g, f, src, dst, tmp, st); break;
-        case 9: launch_fdm<9>(g, f, src, dst, tmp, st); break;
-        case 10: launch_fdm<10>(g, f, src, dst, tmp, st); break;
-        case 11: launch_fdm<11>(g, f, src, dst, tmp, st); break;
-        case 12: launch_fdm<12>(g, f, src, dst, tmp, st); break;
-        case 13: launch_fdm<13>(g, f, src, dst, tmp, st); break;
+        case 2: launch_fdm<2>(g, f, src, dst, tmp, fu, st); break;
+        case 3: launch_fdm<3>(g, f, src, dst, tmp, fu, st); break;
+        case 4: launch_fdm<4>(g, f, src, dst, tmp, fu, st); break;
+        case 5: launch_fdm<5>(g, f, src, dst, tmp, fu, st); break;
+        case 6: launch_fdm<6>(g, f, src, dst, tmp, fu, st); break;
+        case 7: launch_fdm<7>(g, f, src, dst, tmp, fu, st); break;
+        case 8: launch_fdm<8>(g, f, src, dst, tmp, fu, st); break;
+        case 9: launch_fdm<9>(g, f, src, dst, tmp, fu, st); break;
+        case 10: launch_fdm<10>(g, f, src, dst, tmp, fu, st); break;
+        case 11: launch_fdm<11>(g, f, src, dst, tmp, fu, st); break;
+        case 12: launch_fdm<12>(g, f, src, dst, tmp, fu, st); break;
+        case 13: launch_fdm<13>(g, f, src, dst, tmp, fu, st); break;
         default: return false;
       }
     return true;
