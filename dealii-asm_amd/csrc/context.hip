@@ -288,6 +288,28 @@ namespace
         vec_boxes(g, 1, v, ctx->dbuf[1], ctx->drecv, ctx->stream);
         return ASM_OK;
       }
+    static const bool dimension_ordered = std::getenv("ASM_COMPRESS_BY_DIMENSION") != nullptr; // experiments: the three-round form
+    if (add && ctx->n_dmsg > 0 && !dimension_ordered)
+      {
+        // compress(add) in one round, the single-round ghost update run backwards: every ghost box goes straight
+        // to the rank that owns it (face, edge and corner neighbours alike) and is added there; then the
+        // ghost boxes are zeroed (zero_out_ghost_values).  Sends in array order, receives in reverse order:
+        // the pairing argument of the update applies unchanged.
+        vec_boxes(g, 0, v, ctx->dbuf[1], ctx->drecv, ctx->stream);
+        NCCL_TRY(ncclGroupStart());
+        for (int i = 0; i < ctx->n_dmsg; ++i)
+          if (ctx->dmsg[i].recv_count > 0)
+            NCCL_TRY(ncclSend(ctx->dbuf[1] + ctx->dmsg[i].recv_offset, ctx->dmsg[i].recv_count, ncclDouble, ctx->dmsg[i].peer,
+                              ctx->comm, ctx->stream));
+        for (int i = ctx->n_dmsg - 1; i >= 0; --i)
+          if (ctx->dmsg[i].send_count > 0)
+            NCCL_TRY(ncclRecv(ctx->dbuf[0] + ctx->dmsg[i].send_offset, ctx->dmsg[i].send_count, ncclDouble, ctx->dmsg[i].peer,
+                              ctx->comm, ctx->stream));
+        NCCL_TRY(ncclGroupEnd());
+        vec_boxes(g, 2, v, ctx->dbuf[0], ctx->dsend, ctx->stream);
+        vec_boxes(g, 3, v, nullptr, ctx->drecv, ctx->stream);
+        return ASM_OK;
+      }
     asm_exchange_step steps[3];
     const int         n_steps = build_exchange_plan(ctx->s, add, steps);
     for (int i = 0; i < n_steps; ++i)
@@ -1298,6 +1320,21 @@ int
 asm_comm_init(asm_ctx *ctx, const char id[128])
 {
   const DeviceScope device_scope(ctx);
+  if (ctx == nullptr || id == nullptr)
+    {
+      g_create_error = "asm_comm_init: context and unique id must be given";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (ctx->s.prm.world_size < 2)
+    {
+      ctx->error = "asm_comm_init: the context was created for a single rank (world_size = 1)";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (ctx->comm != nullptr || ctx->loop)
+    {
+      ctx->error = "asm_comm_init: the context already has a communicator";
+      return ASM_ERR_INVALID_VALUE;
+    }
   ncclUniqueId uid;
   std::memcpy(&uid, id, 128);
   NCCL_TRY(ncclCommInitRank(&ctx->comm, ctx->s.prm.world_size, uid, ctx->s.prm.rank));
@@ -1804,6 +1841,42 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
         ctxs[r]->error = "asm_debug_exchange_all: ctxs[r] must be rank r of n";
         return ASM_ERR_INVALID_VALUE;
       }
+  static const bool dimension_ordered = std::getenv("ASM_COMPRESS_BY_DIMENSION") != nullptr;
+  if (add && ctxs[0]->n_dmsg > 0 && !dimension_ordered)
+    {
+      // single-round compress(add): the ghost box rank r holds for offset o is added to the box its peer sends
+      // towards -o in the update
+      for (int r = 0; r < n; ++r)
+        vec_boxes(ctxs[r]->g, 0, vecs[r], ctxs[r]->dbuf[1], ctxs[r]->drecv, ctxs[r]->stream);
+      HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
+      for (int r = 0; r < n; ++r)
+        for (int i = 0; i < ctxs[r]->n_dmsg; ++i)
+          {
+            const asm_direct_message &m = ctxs[r]->dmsg[i];
+            if (m.send_count == 0)
+              continue;
+            const asm_ctx *           pc = ctxs[m.peer];
+            const asm_direct_message *pm = nullptr;
+            for (int j = 0; j < pc->n_dmsg; ++j)
+              if (pc->dmsg[j].peer == r && pc->dmsg[j].offset[0] == -m.offset[0] && pc->dmsg[j].offset[1] == -m.offset[1] &&
+                  pc->dmsg[j].offset[2] == -m.offset[2])
+                pm = &pc->dmsg[j];
+            if (pm == nullptr || pm->recv_count != m.send_count)
+              {
+                ctxs[r]->error = "asm_debug_exchange_all: send and receive boxes do not match";
+                return ASM_ERR_INVALID_VALUE;
+              }
+            HIP_TRY_CTX(ctxs[r], hipMemcpy(ctxs[r]->dbuf[0] + m.send_offset, pc->dbuf[1] + pm->recv_offset,
+                                           m.send_count * sizeof(double), hipMemcpyDeviceToDevice));
+          }
+      for (int r = 0; r < n; ++r)
+        {
+          vec_boxes(ctxs[r]->g, 2, vecs[r], ctxs[r]->dbuf[0], ctxs[r]->dsend, ctxs[r]->stream);
+          vec_boxes(ctxs[r]->g, 3, vecs[r], nullptr, ctxs[r]->drecv, ctxs[r]->stream);
+        }
+      HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
+      return ASM_OK;
+    }
   if (!add && ctxs[0]->n_dmsg > 0)
     {
       // single-round plan: what rank r receives from offset o is what its peer sends towards -o

@@ -40,6 +40,12 @@ namespace asmamd
       handle_.reset(h, asm_destroy);
       check(asm_vector_layout(h, &layout_));
     }
+    // a level of a multigrid hierarchy: owned by the asm_mg object, not by this wrapper
+    Context(asm_ctx *borrowed, std::nullptr_t)
+      : handle_(borrowed, [](asm_ctx *) {})
+    {
+      check(asm_vector_layout(borrowed, &layout_));
+    }
     asm_ctx *get() const { return handle_.get(); }
     const asm_layout &layout() const { return layout_; }
     void check(const int err) const
@@ -283,6 +289,66 @@ namespace asmamd
   private:
     const Context &ctx_;
   };
+
+  // ---- the smoother's callers -------------------------------------------------------------------------
+  // PreconditionerGMG / MyMultigrid (include/multigrid.h:40-520, include/precondition.h:82-186): level
+  // operators, smoothers ("mg smoother" = the smoother the fine parameters describe), MGTwoLevelTransfer
+  // between neighbouring levels, coarse-grid solver, one V-cycle per vmult
+  class PreconditionerGMG : public PreconditionerBase<DeviceVector>
+  {
+  public:
+    PreconditionerGMG(const asm_params &fine, const asm_mg_params &mp)
+    {
+      asm_mg *h = nullptr;
+      if (const int err = asm_mg_create(&fine, &mp, &h))
+        throw std::runtime_error("asm_mg_create failed (" + std::to_string(err) + "): " + asm_mg_last_error(nullptr));
+      handle_.reset(h, asm_mg_destroy);
+      int32_t n = 0;
+      asm_mg_n_levels(h, &n);
+      for (int32_t l = 0; l < n; ++l)
+        {
+          asm_ctx *c = nullptr;
+          check(asm_mg_level_context(h, l, &c));
+          levels_.emplace_back(new Context(c, nullptr));
+        }
+    }
+    asm_mg *       get() const { return handle_.get(); }
+    unsigned int   n_levels() const { return levels_.size(); }
+    const Context &level(const unsigned int l) const { return *levels_[l]; }   // mg_operators[l]
+    const Context &fine() const { return *levels_.back(); }
+    void vmult(DeviceVector &dst, const DeviceVector &src) const override { check(asm_mg_vmult(handle_.get(), dst.data(), src.data())); }
+    // MGTwoLevelTransfer between level and level - 1 (include/multigrid.h:289-299, 336-346)
+    void prolongate_and_add(const unsigned int level, DeviceVector &dst_fine, const DeviceVector &src_coarse) const
+    {
+      check(asm_mg_prolongate_add(handle_.get(), (int32_t)level, dst_fine.data(), src_coarse.data()));
+    }
+    void restrict_and_add(const unsigned int level, DeviceVector &dst_coarse_zeroed, const DeviceVector &src_fine) const
+    {
+      check(asm_mg_restrict(handle_.get(), (int32_t)level, dst_coarse_zeroed.data(), src_fine.data()));
+    }
+    void check(const int err) const
+    {
+      if (err)
+        throw std::runtime_error(std::string("dealii_asm_amd multigrid: ") + asm_mg_last_error(handle_.get()));
+    }
+
+  private:
+    std::shared_ptr<asm_mg>               handle_;
+    std::vector<std::unique_ptr<Context>> levels_;
+  };
+
+  // solve(), element_centered_preconditioners_01.cc:108-263: x = 0, SolverCG / SolverGMRES under ReductionControl;
+  // returns SolverControl::last_step() and the residuals
+  inline asm_solver_result
+  solve(const Context &fine, DeviceVector &x, const DeviceVector &b, const int system_preconditioner, const asm_solver_params &sp,
+        const PreconditionerGMG *mg = nullptr)
+  {
+    asm_solver_result res;
+    const int err = asm_solve(fine.get(), mg ? mg->get() : nullptr, system_preconditioner, &sp, x.data(), b.data(), &res);
+    if (err)
+      throw std::runtime_error(std::string("asm_solve: ") + (mg ? asm_mg_last_error(mg->get()) : asm_last_error(fine.get())));
+    return res;
+  }
 } // namespace asmamd
 
 #endif

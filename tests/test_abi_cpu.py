@@ -124,3 +124,13 @@ def test_params_set_accepts_reference_keys_and_rejects_unknown(pkg):
     q = pkg.make_params(smoothing_range=1.0)
     with pytest.raises(ValueError):
         pkg.describe_layout(q)
+
+
+def test_comm_init_error_path(pkg):
+    """asm_comm_init without a context / id is an error code, not a crash (the only part of the RCCL bootstrap that
+    can be walked without a GPU)"""
+    import ctypes as C
+
+    lib = pkg.load_library()
+    assert lib.asm_comm_init(None, b"\0" * 128) == 1
+    assert "context and unique id" in lib.asm_last_error(None).decode()

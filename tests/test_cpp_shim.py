@@ -48,3 +48,18 @@ def test_fused_driver_matches_step_bitwise_on_gpu(pkg, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bitwise identical" in r.stdout
+
+
+def test_multigrid_driver_compiles_and_refuses_without_gpu(pkg, tmp_path):
+    pkg.load_library()
+    exe = _build(tmp_path, "multigrid_solve")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode in (0, 77), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_multigrid_driver_converges_on_gpu(pkg, tmp_path):
+    exe = _build(tmp_path, "multigrid_solve")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GMRES it" in r.stdout

@@ -72,6 +72,34 @@ def _run_direct_plan(msgs, box, layout):
         view(list(m.recv_lo), list(m.recv_size))[...] = buf.numpy()
 
 
+def _run_direct_compress(msgs, box, layout):
+    """single-round compress(add): the update's plan run backwards (every ghost box straight to its owner, added
+    there, ghost boxes zeroed afterwards); sends in array order, receives in reverse order"""
+    lo0 = [layout.store_begin[d] for d in range(3)]
+
+    def view(lo, size):
+        sl = tuple(slice(lo[d] - lo0[d], lo[d] - lo0[d] + size[d]) for d in (2, 1, 0))
+        return box[sl]
+
+    reqs, recv_bufs = [], []
+    for m in msgs:
+        if m.recv_count > 0:
+            buf = torch.from_numpy(np.ascontiguousarray(view(list(m.recv_lo), list(m.recv_size))))
+            reqs.append(dist.isend(buf, m.peer))
+    for m in reversed(msgs):
+        if m.send_count > 0:
+            buf = torch.empty(tuple(m.send_size[d] for d in (2, 1, 0)), dtype=torch.float64)
+            recv_bufs.append((m, buf))
+            reqs.append(dist.irecv(buf, m.peer))
+    for r in reqs:
+        r.wait()
+    for m, buf in recv_bufs:
+        view(list(m.send_lo), list(m.send_size))[...] += buf.numpy()
+    for m in msgs:
+        if m.recv_count > 0:
+            view(list(m.recv_lo), list(m.recv_size))[...] = 0.0
+
+
 def _worker(rank, world, port, case, result_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -157,10 +185,17 @@ def _worker(rank, world, port, case, result_q):
                             if L.proc_grid[d] == 1:
                                 loc[d] %= nc[d] * p
                     acc[loc[2] - lo0[2], loc[1] - lo0[1], loc[0] - lo0[0]] += T[c, k, j, i]
+    acc2 = acc.copy()
     _run_plan(pkg.exchange_plan(prm, True), acc, L, add=True)
+    _run_direct_compress(pkg.exchange_plan_direct(prm), acc2, L)
     got = acc[osl]
     want = glob(ref)[gsl]
     err = float(np.abs(got - want).max() / np.abs(ref).max())
+    # the single-round form: same owned values (up to the order of the additions), ghost boxes zeroed
+    err = max(err, float(np.abs(acc2[osl] - want).max() / np.abs(ref).max()))
+    ghost = np.ones(acc2.shape, bool)
+    ghost[osl] = False
+    err = max(err, float(np.abs(acc2[ghost]).max()) if ghost.any() else 0.0)
     result_q.put((rank, ok_update, err))
     dist.barrier()
     dist.destroy_process_group()
@@ -179,7 +214,7 @@ CASES = [
 
 @pytest.mark.parametrize(
     "world,case",
-    [(w, c) for w in (2, 4) for c in CASES] + [(8, CASES[4]), (8, CASES[5])],
+    [(w, c) for w in (2, 4) for c in CASES] + [(8, CASES[1]), (8, CASES[4]), (8, CASES[5])],
     ids=lambda v: str(v) if isinstance(v, int) else f"{v[2]}-{v[3]}",
 )
 def test_exchange_plan_gloo(case, world):
