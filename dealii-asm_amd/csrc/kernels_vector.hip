@@ -229,15 +229,19 @@ namespace asmamd
       const int       b  = blockIdx.y;
       const int       s0 = bl.size[b][0], s1 = bl.size[b][1], s2 = bl.size[b][2];
       const long long n  = (long long)s0 * s1 * s2;
-      double *        bb = buf + bl.offset[b];
+      double *        bb = buf + (mode == 3 ? 0 : bl.offset[b]);
       for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
         {
           const int       i = (int)(e % s0), j = (int)((e / s0) % s1), k = (int)(e / ((long long)s0 * s1));
           const long long o = g.offset(bl.lo[b][0] + i, bl.lo[b][1] + j, bl.lo[b][2] + k);
           if (mode == 0)
             bb[e] = vec[o];
-          else
+          else if (mode == 1)
             vec[o] = bb[e];
+          else if (mode == 2)
+            unsafeAtomicAdd(&vec[o], bb[e]); // the boxes of a compress(add) overlap in the owned region (faces, edges, corners)
+          else
+            vec[o] = 0.;
         }
     }
   } // namespace

@@ -30,13 +30,14 @@ def main():
     ap.add_argument("--rel-tol", type=float, default=1e-5)
     ap.add_argument("--tmp-vectors", type=int, default=17)
     ap.add_argument("--best-of", type=int, default=5)
+    ap.add_argument("--coarse", default="cg", choices=["cg", "smoother"])
     args = ap.parse_args()
     pkg = load_package()
     prm = pkg.make_params(degree=4, n_cells=args.cells, boundary="dirichlet", geometry=args.geometry, kershaw_eps=(0.3, 0.3),
                           weighting=args.weighting, n_overlap=args.n_overlap, element_centric=args.patch == "cell",
                           cheb_degree=args.degree)
     t0 = time.perf_counter()
-    mg = pkg.Multigrid(prm, mg_type=args.mg_type, coarse="cg", coarse_rel_tol=1e-3)
+    mg = pkg.Multigrid(prm, mg_type=args.mg_type, coarse=args.coarse, coarse_rel_tol=1e-3)
     fine = mg.fine
     fine.synchronize()
     t_setup = time.perf_counter() - t0
@@ -64,7 +65,7 @@ def main():
     t_v = (time.perf_counter() - t0) / 5
     levels = [(c.n_dofs) for c in mg.levels]
     print(f"cells {args.cells} {args.geometry} n_dofs {fine.n_dofs} levels {levels} {args.solver} k={args.degree} {args.weighting} "
-          f"n_overlap={args.n_overlap} patch={args.patch}: it {res.n_iterations} converged {res.converged} "
+          f"n_overlap={args.n_overlap} patch={args.patch} coarse={args.coarse}: it {res.n_iterations} converged {res.converged} "
           f"time {best:.4e} s  (V-cycle {t_v * 1e3:.3f} ms, setup {t_setup:.2f} s)")
 
 
