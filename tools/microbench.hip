@@ -37,6 +37,21 @@ __global__ void __launch_bounds__(256) copy_kernel(double2 *dst, const double2 *
 {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) dst[i] = src[i];
 }
+// four 16-byte loads in flight per lane before the first store, streaming (non-temporal) accesses
+typedef double v2d __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) copy4_kernel(v2d *dst, const v2d *src, long long n)
+{
+  const long long stride = gridDim.x * 256ll;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i + 3 * stride < n; i += 4 * stride)
+    {
+      const v2d v0 = __builtin_nontemporal_load(src + i), v1 = __builtin_nontemporal_load(src + i + stride),
+                    v2 = __builtin_nontemporal_load(src + i + 2 * stride), v3 = __builtin_nontemporal_load(src + i + 3 * stride);
+      __builtin_nontemporal_store(v0, dst + i);
+      __builtin_nontemporal_store(v1, dst + i + stride);
+      __builtin_nontemporal_store(v2, dst + i + 2 * stride);
+      __builtin_nontemporal_store(v3, dst + i + 3 * stride);
+    }
+}
 __global__ void __launch_bounds__(256) triad_kernel(double2 *dst, const double2 *a, const double2 *b, long long n)
 {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
@@ -78,5 +93,15 @@ int main()
       hipEventElapsedTime(&ms, e0, e1);
       printf("triad blocks=%d: %.2f TB/s\n", blocks, 3.0 * n * 16 / ms / 1e9);
     }
+  // the same copy with 4 loads in flight per lane and streaming accesses, at several working-set sizes (a set that
+  // fits the 256 MiB Infinity Cache is served on-die: not an HBM rate)
+  for (long long m : {1ll << 23, 1ll << 25, 1ll << 27})
+    for (int blocks : {4096, 16384})
+      {
+        for (int rep = 0; rep < 5; ++rep)
+          { hipEventRecord(e0); copy4_kernel<<<blocks, 256>>>((v2d *)c, (const v2d *)a, m); hipEventRecord(e1); hipEventSynchronize(e1); }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("copy4 (x4 unrolled, nontemporal) %5lld MiB per array, blocks=%d: %.2f TB/s\n", m * 16 >> 20, blocks, 2.0 * m * 16 / ms / 1e9);
+      }
   return 0;
 }

@@ -2,7 +2,8 @@
 # usage (on the GPU box, from the repo root): tools/pmc.sh "<counters pass 1>" "<counters pass 2>" ...
 # Runs `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` under rocprofv3 --pmc, one pass per
 # argument (counter collection only, no tracing), and prints the mean counter value per dispatch
-# of the two tiled kernels.
+# of every sweep kernel variant that ran (ASM_TILED_ROWS=0 keeps the context from launching the other
+# Laplace variants while it tunes).
 R=$PWD
 export ASM_BENCH_LAMBDA=1.7
 cd /tmp && export TMPDIR=/tmp
@@ -13,16 +14,18 @@ for c in "$@"; do
 done
 cd $R
 python3 - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, re
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob('gpurun_out/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        name = 'laplace' if 'laplace_cart_tiled' in k else ('fdm' if 'fdm_tiled' in k else None)
-        if name is None:
+        if 'laplace_cart_tiled' not in k and 'fdm_tiled' not in k and 'laplace_generic' not in k and 'fdm_generic' not in k:
             continue
+        # kernel name with its template arguments, without the parameter list (the context's tuning launches of
+        # other kernel variants stay separate rows)
+        name = re.search(r'(\w+(<[^>]*>)?)\(asmamd::DevGrid', k).group(1)
         a = acc[(name, r['Counter_Name'])]
         a[0] += float(r['Counter_Value']); a[1] += 1
 for (k, c), (v, n) in sorted(acc.items()):
-    print(f"{k:8s} {c:28s} {v / n:14.4g}  (n={n})")
+    print(f"{k:44s} {c:28s} {v / n:14.4g}  (n={n})")
 PY

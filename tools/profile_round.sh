@@ -1,8 +1,11 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/profile_round.sh  -> everything under gpurun_out/prof_round/
+# bench lines of the default and the other workloads, rocprofv3 kernel trace + stats of the default bench command,
+# HBM traffic (FETCH_SIZE / WRITE_SIZE in separate counter-only passes)
 set -e
 R=$PWD
 O=$R/gpurun_out/prof_round
+rm -rf $O
 mkdir -p $O
 python bench.py > $O/bench_default.json
 for w in "--workload cart_periodic" "--workload kershaw" "--degree 3" "--cells 128 128 96"; do
@@ -13,3 +16,4 @@ rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/benc
 cd $R
 tools/pmc.sh "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_traffic.txt
 find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+rm -rf $O/kt gpurun_out/pmc_1 gpurun_out/pmc_2
