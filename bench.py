@@ -49,9 +49,8 @@ def algorithmic_bytes_per_dof(degree, what):
 
 def cpu_baseline(args, pkg, cells):
     """The same smoother application on the host cores, on a bounded sample of the workload.
-    Cartesian workloads: the threaded C++ restatement oracle/asm_oracle_cpu.cc (kind "port",
-    checked against the numpy oracle in tests/test_oracle_cpu_port.py), all host threads.
-    Kershaw: the numpy oracle on one core."""
+    The threaded C++ restatement oracle/asm_oracle_cpu.cc (kind "port", checked against the numpy oracle in
+    tests/test_oracle_cpu_port.py) on every host core this process may use."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import asm_oracle as orc
 
@@ -88,29 +87,34 @@ def cpu_baseline(args, pkg, cells):
             f"({sm.n_dofs} DoFs, the bench mesh), C++ restatement oracle/asm_oracle_cpu.cc, {threads} threads "
             f"(os.cpu_count()={os.cpu_count()}, usable={usable})",
         }
-    nc = (12, 12, 12)
+    # Kershaw: the threaded C++ restatement with per-cell tri-quadratic geometry and eigen-decompositions (checked
+    # against the numpy oracle in tests/test_oracle_cpu_port.py); its tables come from the numpy oracle, whose setup
+    # loops over the cells in Python, hence the smaller sample mesh
+    import asm_oracle_cpu
+
+    threads = max(1, usable if args.cpu_threads <= 0 else min(usable, args.cpu_threads))
+    nc = (24, 24, 24)
     mesh = orc.Mesh(nc, 4, [orc.DIRICHLET] * 3, mapfn=lambda pts: orc.kershaw(0.3, 0.3, pts))
-    op = orc.LaplaceOperator(mesh)
-    prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
-    cheb = orc.Chebyshev(op, prec, degree=args.degree, lambda_max=1.8)
+    sm = asm_oracle_cpu.CpuSmootherDeformed(mesh, degree=args.degree, lambda_max=1.8, n_threads=threads)
     b = np.ones(mesh.n_dofs)
-    x = cheb.step(np.zeros(mesh.n_dofs), b)  # warm-up
+    x = sm.step(np.zeros(mesh.n_dofs), b, reps=2)  # warm-up
+    per_call = 16
     reps, t0 = 0, time.perf_counter()
     while True:
-        x = cheb.step(x, b)
-        reps += 1
+        x = sm.step(x, b, reps=per_call)
+        reps += per_call
         el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 50:
+        if el > 10.0 or reps >= 4000:
             break
     return {
         "value": mesh.n_dofs * reps / el,
         "unit": "DoF/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "port",
         "host_cpu_count": os.cpu_count(),
         "host_cpus_usable": usable,
         "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} Kershaw cells p=4 "
-        f"({mesh.n_dofs} DoFs), numpy oracle, 1 thread",
+        f"({mesh.n_dofs} DoFs), C++ restatement oracle/asm_oracle_cpu.cc (deformed-cell leg), {threads} threads",
     }
 
 

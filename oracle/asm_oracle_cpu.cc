@@ -39,7 +39,17 @@ namespace
     const int *   inst[3];                 // [nc[d]]
     const double *eig;                     // [n_inst][30]
     const double *wpost[3];                // [nc[d]][5]
+    // deformed meshes (per-cell data, cells numbered x fastest); nullptr on Cartesian meshes
+    const double *q2_coeff = nullptr;      // [cell][27][3] monomial coefficients of the tri-quadratic map, index 9k+3j+i
+    const double *cell_eig = nullptr;      // [cell][3][30]: Q (row i, col a) then lambda, per direction
+    const double *cell_wpost = nullptr;    // [cell][125] post weights of the cell's patch
+    const double *xq = nullptr;            // [5] quadrature points
   };
+  inline long
+  cell_index(const Problem &p, const int cx, const int cy, const int cz)
+  {
+    return cx + (long)p.nc[0] * (cy + (long)p.nc[1] * cz);
+  }
 
   inline long
   dof(const Problem &p, int I, int J, int K)
@@ -188,6 +198,95 @@ namespace
     scatter_add(p, bt, u, dst, sign);
   }
 
+
+  // dst += sign * A_cell src on deformed cells ("quadratic geometry", include/operator.h:1035-1159): the Jacobian of
+  // the tri-quadratic map is evaluated from the 27 coefficient vectors per cell by collapsing z, then y, then x (the
+  // reference's order, :1101-1128), inverted per quadrature point (do_invert, :891-914) and applied as
+  // J^-1 J^-T det w to the reference gradient (:1132-1152)
+  void
+  laplace_batch_deformed(const Problem &p, const Batch &bt, const double *src, double *dst, const double sign)
+  {
+    alignas(64) double u[NE][VL], g[3][NE][VL];
+    gather<true>(p, bt, src, u);
+    for (int d = 0; d < 3; ++d)
+      sweep<false>(p.N, d, u);
+    for (int d = 0; d < 3; ++d)
+      {
+        std::memcpy(g[d], u, sizeof(u));
+        sweep<false>(p.Dc, d, g[d]);
+      }
+    for (int v = 0; v < VL; ++v)
+      {
+        const int     vc = v < bt.n ? v : 0;
+        const double *c  = p.q2_coeff + cell_index(p, bt.c[vc][0], bt.c[vc][1], bt.c[vc][2]) * 81;
+        for (int qz = 0; qz < N1; ++qz)
+          {
+            const double z = p.xq[qz];
+            double       a[9][3], az[9][3]; // value / z-derivative, index 3j+i
+            for (int ji = 0; ji < 9; ++ji)
+              for (int e = 0; e < 3; ++e)
+                {
+                  const double c0 = c[(0 * 9 + ji) * 3 + e], c1 = c[(1 * 9 + ji) * 3 + e], c2 = c[(2 * 9 + ji) * 3 + e];
+                  a[ji][e]  = c0 + z * (c1 + z * c2);
+                  az[ji][e] = c1 + 2. * z * c2;
+                }
+            for (int qy = 0; qy < N1; ++qy)
+              {
+                const double y = p.xq[qy];
+                double       b[3][3], by[3][3], bz[3][3]; // index i
+                for (int i = 0; i < 3; ++i)
+                  for (int e = 0; e < 3; ++e)
+                    {
+                      b[i][e]  = a[0 * 3 + i][e] + y * (a[1 * 3 + i][e] + y * a[2 * 3 + i][e]);
+                      by[i][e] = a[1 * 3 + i][e] + 2. * y * a[2 * 3 + i][e];
+                      bz[i][e] = az[0 * 3 + i][e] + y * (az[1 * 3 + i][e] + y * az[2 * 3 + i][e]);
+                    }
+                for (int qx = 0; qx < N1; ++qx)
+                  {
+                    const double x = p.xq[qx];
+                    double       J[3][3];
+                    for (int e = 0; e < 3; ++e)
+                      {
+                        J[0][e] = b[1][e] + 2. * x * b[2][e];
+                        J[1][e] = by[0][e] + x * (by[1][e] + x * by[2][e]);
+                        J[2][e] = bz[0][e] + x * (bz[1][e] + x * bz[2][e]);
+                      }
+                    // inverse (adjugate / determinant)
+                    const double t00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], t10 = J[1][2] * J[2][0] - J[1][0] * J[2][2],
+                                 t20 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+                    const double det = J[0][0] * t00 + J[0][1] * t10 + J[0][2] * t20, inv = 1. / det;
+                    double       G[3][3];
+                    G[0][0] = inv * t00;
+                    G[0][1] = inv * (J[0][2] * J[2][1] - J[0][1] * J[2][2]);
+                    G[0][2] = inv * (J[0][1] * J[1][2] - J[0][2] * J[1][1]);
+                    G[1][0] = inv * t10;
+                    G[1][1] = inv * (J[0][0] * J[2][2] - J[0][2] * J[2][0]);
+                    G[1][2] = inv * (J[0][2] * J[1][0] - J[0][0] * J[1][2]);
+                    G[2][0] = inv * t20;
+                    G[2][1] = inv * (J[0][1] * J[2][0] - J[0][0] * J[2][1]);
+                    G[2][2] = inv * (J[0][0] * J[1][1] - J[0][1] * J[1][0]);
+                    const int    q  = (qz * N1 + qy) * N1 + qx;
+                    const double dw = det * p.wq[qx] * p.wq[qy] * p.wq[qz];
+                    const double gx = g[0][q][v], gy = g[1][q][v], gz = g[2][q][v];
+                    const double t0 = (G[0][0] * gx + G[0][1] * gy + G[0][2] * gz) * dw, t1 = (G[1][0] * gx + G[1][1] * gy + G[1][2] * gz) * dw,
+                                 t2 = (G[2][0] * gx + G[2][1] * gy + G[2][2] * gz) * dw;
+                    g[0][q][v] = G[0][0] * t0 + G[1][0] * t1 + G[2][0] * t2;
+                    g[1][q][v] = G[0][1] * t0 + G[1][1] * t1 + G[2][1] * t2;
+                    g[2][q][v] = G[0][2] * t0 + G[1][2] * t1 + G[2][2] * t2;
+                  }
+              }
+          }
+      }
+    for (int d = 0; d < 3; ++d)
+      sweep<true>(p.Dc, d, g[d]);
+    for (int e = 0; e < NE; ++e)
+      for (int v = 0; v < VL; ++v)
+        u[e][v] = g[0][e][v] + g[1][e][v] + g[2][e][v];
+    for (int d = 0; d < 3; ++d)
+      sweep<true>(p.N, d, u);
+    scatter_add(p, bt, u, dst, sign);
+  }
+
   // dst += P_cell^-1 src
   void
   fdm_batch(const Problem &p, const Batch &bt, const double *src, double *dst)
@@ -198,10 +297,13 @@ namespace
     for (int d = 0; d < 3; ++d)
       for (int v = 0; v < VL; ++v)
         {
-          const int c = bt.c[v < bt.n ? v : 0][d];
-          Q[d][v]     = p.eig + (long)p.inst[d][c] * 30;
-          lam[d][v]   = Q[d][v] + 25;
-          w[d][v]     = p.wpost[d] + (long)c * N1;
+          const int vc = v < bt.n ? v : 0, c = bt.c[vc][d];
+          if (p.cell_eig)
+            Q[d][v] = p.cell_eig + (cell_index(p, bt.c[vc][0], bt.c[vc][1], bt.c[vc][2]) * 3 + d) * 30;
+          else
+            Q[d][v] = p.eig + (long)p.inst[d][c] * 30;
+          lam[d][v] = Q[d][v] + 25;
+          w[d][v]   = p.cell_eig ? nullptr : p.wpost[d] + (long)c * N1;
         }
     for (int d = 0; d < 3; ++d)
       sweep_q<true>(Q[d], d, t);
@@ -212,11 +314,22 @@ namespace
             t[(k * N1 + j) * N1 + i][v] /= lam[0][v][i] + (lam[1][v][j] + lam[2][v][k]);
     for (int d = 0; d < 3; ++d)
       sweep_q<false>(Q[d], d, t);
-    for (int k = 0; k < N1; ++k)
-      for (int j = 0; j < N1; ++j)
-        for (int i = 0; i < N1; ++i)
-          for (int v = 0; v < VL; ++v)
-            t[(k * N1 + j) * N1 + i][v] *= w[0][v][i] * (w[1][v][j] * w[2][v][k]);
+    if (p.cell_eig)
+      {
+        for (int v = 0; v < VL; ++v)
+          {
+            const int     vc = v < bt.n ? v : 0;
+            const double *wc = p.cell_wpost + cell_index(p, bt.c[vc][0], bt.c[vc][1], bt.c[vc][2]) * NE;
+            for (int e = 0; e < NE; ++e)
+              t[e][v] *= wc[e];
+          }
+      }
+    else
+      for (int k = 0; k < N1; ++k)
+        for (int j = 0; j < N1; ++j)
+          for (int i = 0; i < N1; ++i)
+            for (int v = 0; v < VL; ++v)
+              t[(k * N1 + j) * N1 + i][v] *= w[0][v][i] * (w[1][v][j] * w[2][v][k]);
     scatter_add(p, bt, t, dst, 1.0);
   }
 
@@ -354,37 +467,13 @@ namespace
   }
 } // namespace
 
-extern "C" {
-
-// x <- Chebyshev step (degree k, first kind) with the FDM preconditioner, `reps` times
-int
-oracle_cpu_cheb_step(const int *nc, const int *periodic, const double *h, const double *N, const double *Dc, const double *wq,
-                     const int *inst_x, const int *inst_y, const int *inst_z, const double *eig, const double *wpost_x,
-                     const double *wpost_y, const double *wpost_z, const int degree, const double theta, const double delta,
-                     double *x, const double *b, const int n_threads, const int reps)
+namespace
 {
-  Problem p;
-  long    n = 1;
-  for (int d = 0; d < 3; ++d)
-    {
-      p.nc[d]       = nc[d];
-      p.periodic[d] = periodic[d];
-      p.nu[d]       = nc[d] * P + (periodic[d] ? 0 : 1);
-      p.h[d]        = h[d];
-      n *= p.nu[d];
-      if (periodic[d] && (nc[d] % 2))
-        return 1; // the 2x2x2 colouring needs an even number of cells in periodic directions
-    }
-  p.N        = N;
-  p.Dc       = Dc;
-  p.wq       = wq;
-  p.inst[0]  = inst_x;
-  p.inst[1]  = inst_y;
-  p.inst[2]  = inst_z;
-  p.eig      = eig;
-  p.wpost[0] = wpost_x;
-  p.wpost[1] = wpost_y;
-  p.wpost[2] = wpost_z;
+  int
+  cheb_step(const Problem &p, const int degree, const double theta, const double delta, double *x, const double *b, const int n_threads,
+            const int reps)
+  {
+  const long n = (long)p.nu[0] * p.nu[1] * p.nu[2];
   Pool               pool(n_threads < 1 ? 1 : n_threads);
   std::vector<Batch> colours[8];
   for (int c = 0; c < 8; ++c)
@@ -412,7 +501,10 @@ oracle_cpu_cheb_step(const int *nc, const int *periodic, const double *h, const 
       for (long i = i0; i < i1; ++i)
         r[i] = con[i] ? bw[i] - xx[i] : bw[i];
     });
-    cell_loop(pool, colours, [&](const Batch &bt) { laplace_batch(p, bt, xx, r, -1.0); });
+    if (p.q2_coeff)
+      cell_loop(pool, colours, [&](const Batch &bt) { laplace_batch_deformed(p, bt, xx, r, -1.0); });
+    else
+      cell_loop(pool, colours, [&](const Batch &bt) { laplace_batch(p, bt, xx, r, -1.0); });
   };
   const auto precondition = [&]() {
     vector_loop(pool, n, [&](const long i0, const long i1) {
@@ -462,5 +554,70 @@ oracle_cpu_cheb_step(const int *nc, const int *periodic, const double *h, const 
   std::free(xo);
   std::free(con);
   return 0;
+  }
+
+  int
+  fill_problem(Problem &p, const int *nc, const int *periodic, const double *h)
+  {
+    for (int d = 0; d < 3; ++d)
+      {
+        p.nc[d]       = nc[d];
+        p.periodic[d] = periodic[d];
+        p.nu[d]       = nc[d] * P + (periodic[d] ? 0 : 1);
+        p.h[d]        = h[d];
+        if (periodic[d] && (nc[d] % 2))
+          return 1; // the 2x2x2 colouring needs an even number of cells in periodic directions
+      }
+    return 0;
+  }
+} // namespace
+
+extern "C" {
+
+// x <- Chebyshev step (degree k, first kind) with the FDM preconditioner, `reps` times; Cartesian mesh
+int
+oracle_cpu_cheb_step(const int *nc, const int *periodic, const double *h, const double *N, const double *Dc, const double *wq,
+                     const int *inst_x, const int *inst_y, const int *inst_z, const double *eig, const double *wpost_x,
+                     const double *wpost_y, const double *wpost_z, const int degree, const double theta, const double delta,
+                     double *x, const double *b, const int n_threads, const int reps)
+{
+  Problem p;
+  if (fill_problem(p, nc, periodic, h))
+    return 1;
+  p.N        = N;
+  p.Dc       = Dc;
+  p.wq       = wq;
+  p.inst[0]  = inst_x;
+  p.inst[1]  = inst_y;
+  p.inst[2]  = inst_z;
+  p.eig      = eig;
+  p.wpost[0] = wpost_x;
+  p.wpost[1] = wpost_y;
+  p.wpost[2] = wpost_z;
+  return cheb_step(p, degree, theta, delta, x, b, n_threads, reps);
+}
+
+// the same on a deformed (tri-quadratic) Dirichlet mesh with per-cell eigen-decompositions and patch weights
+int
+oracle_cpu_cheb_step_deformed(const int *nc, const double *N, const double *Dc, const double *wq, const double *xq,
+                              const double *q2_coeff, const double *cell_eig, const double *cell_wpost, const int degree,
+                              const double theta, const double delta, double *x, const double *b, const int n_threads, const int reps)
+{
+  Problem      p;
+  const int    periodic[3] = {0, 0, 0};
+  const double h[3]        = {1., 1., 1.};
+  if (fill_problem(p, nc, periodic, h))
+    return 1;
+  p.N          = N;
+  p.Dc         = Dc;
+  p.wq         = wq;
+  p.xq         = xq;
+  p.inst[0] = p.inst[1] = p.inst[2] = nullptr;
+  p.eig                             = nullptr;
+  p.wpost[0] = p.wpost[1] = p.wpost[2] = nullptr;
+  p.q2_coeff                           = q2_coeff;
+  p.cell_eig                           = cell_eig;
+  p.cell_wpost                         = cell_wpost;
+  return cheb_step(p, degree, theta, delta, x, b, n_threads, reps);
 }
 }

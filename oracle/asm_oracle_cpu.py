@@ -74,3 +74,40 @@ class CpuSmoother:
         if err:
             raise RuntimeError("oracle_cpu_cheb_step failed (odd number of cells in a periodic direction?)")
         return x
+
+
+class CpuSmootherDeformed:
+    """Chebyshev(k) + FDM (n_overlap=1, post weights) on a deformed Dirichlet mesh (tri-quadratic geometry), degree 4:
+    per-cell map coefficients, eigen-decompositions and patch weights come from the numpy oracle's objects."""
+
+    def __init__(self, mesh, degree=3, lambda_max=1.8, smoothing_range=20.0, n_threads=1):
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} missing: run `make -C oracle`")
+        assert mesh.p == 4 and mesh.dim == 3 and not any(mesh.periodic)
+        self.lib = C.CDLL(LIB)
+        self.nc = np.array(mesh.nc, dtype=np.int32)
+        self.degree, self.n_threads, self.n_dofs = degree, n_threads, mesh.n_dofs
+        max_ev = 1.2 * lambda_max
+        min_ev = max_ev / smoothing_range
+        self.theta, self.delta = 0.5 * (max_ev + min_ev), 0.5 * (max_ev - min_ev)
+        b = mesh.basis
+        self.N = np.ascontiguousarray(b.N)
+        _, Dc = orc.lagrange_eval(b.xq, b.xq)
+        self.Dc, self.wq, self.xq = np.ascontiguousarray(Dc), np.ascontiguousarray(b.wq), np.ascontiguousarray(b.xq)
+        op = orc.LaplaceOperator(mesh)
+        prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
+        self.q2 = np.ascontiguousarray(op.q2_coeff.reshape(mesh.ncells, 81))  # [cell][9k+3j+i][e]
+        eig = np.concatenate([prec.Q.reshape(mesh.ncells, 3, 25), prec.lam.reshape(mesh.ncells, 3, 5)], axis=2)
+        self.eig = np.ascontiguousarray(eig)  # [cell][d][Q(i, a) row-major | lambda]
+        self.wpost = np.ascontiguousarray(prec.w_post.reshape(mesh.ncells, 125))
+
+    def step(self, x, b, reps=1):
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        err = self.lib.oracle_cpu_cheb_step_deformed(
+            _ptr(self.nc, C.c_int32), _ptr(self.N), _ptr(self.Dc), _ptr(self.wq), _ptr(self.xq), _ptr(self.q2), _ptr(self.eig),
+            _ptr(self.wpost), C.c_int(self.degree), C.c_double(self.theta), C.c_double(self.delta), _ptr(x), _ptr(b),
+            C.c_int(self.n_threads), C.c_int(reps))
+        if err:
+            raise RuntimeError("oracle_cpu_cheb_step_deformed failed")
+        return x

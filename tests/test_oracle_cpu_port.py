@@ -37,3 +37,20 @@ def test_cpu_port_matches_numpy_oracle(cpu_mod, periodic, degree, threads):
     got = sm.step(x0, b)
     ref = cheb.step(x0, b)
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-12
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_cpu_port_deformed_matches_numpy_oracle(cpu_mod, degree, threads):
+    """the threaded deformed-mesh leg (cpu_baseline of the Kershaw workload) against the numpy oracle"""
+    nc = (6, 4, 2)
+    mesh = orc.Mesh(nc, 4, [orc.DIRICHLET] * 3, mapfn=lambda pts: orc.kershaw(0.3, 0.3, pts))
+    op = orc.LaplaceOperator(mesh)
+    prec = orc.ASPoissonPreconditioner(mesh, 1, "post")
+    cheb = orc.Chebyshev(op, prec, degree=degree, lambda_max=1.8)
+    rng = np.random.default_rng(4)
+    x0, b = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+    sm = cpu_mod.CpuSmootherDeformed(mesh, degree=degree, lambda_max=1.8, n_threads=threads)
+    got = sm.step(x0, b)
+    ref = cheb.step(x0, b)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-12
