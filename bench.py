@@ -297,6 +297,13 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, pkg, cells)
+        # the line the reference harness prints for the same run (matrix_free_loop_08.likwid.cc:390-395:
+        # ">> label n_dofs reps time sizeof(Number) degree n_ghost n_import", label DSL :108-144, 249-298:
+        # cheby-<degree>-<optimize>-<weight>-<n_overlap | v>-<weight sequence>); on stderr: stdout carries the JSON line only
+        label = (f"cheby-{args.degree}-2-{'add' if args.weighting == 'none' else args.weighting}-"
+                 f"{'v' if args.patch == 'vertex' else args.n_overlap}-c")
+        print(f">> {label} {n_dofs} {args.steps * args.degree} {elapsed:.6e} 8 4 {int(ctx.layout.n_ghost)} {int(ctx.layout.n_ghost)}",
+              file=sys.stderr)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
