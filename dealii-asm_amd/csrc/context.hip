@@ -1143,6 +1143,59 @@ asm_create(const asm_params *p, asm_ctx **out)
                         1.0 / (s.eig[(size_t)ix * E + m * m + a] + (s.eig[(size_t)iy * E + m * m + b] + s.eig[(size_t)iz * E + m * m + c]));
           UP(inv, &f.inv_table);
         }
+      // 7^3 patches on a tensor-product mesh: the box of cells that share one parity-sorted instance per direction
+      // (all cells but those next to a boundary) goes to the slice-per-lane kernel (kernels_slice7.hip)
+      f.s7_on = 0;
+      if (s.tensor_inst && s.m == 7 && !s.fdm_tiled && std::getenv("ASM_NO_SLICE7") == nullptr)
+        {
+          bool ok = true;
+          for (int d = 0; d < 3 && ok; ++d)
+            {
+              // longest run of cells with one parity-sorted instance
+              int best_lo = 0, best_len = 0;
+              for (int c = 0; c < s.g.nc[d];)
+                {
+                  const int id = s.inst[d][c + 1];
+                  int       e  = c;
+                  while (e < s.g.nc[d] && s.inst[d][e + 1] == id)
+                    ++e;
+                  if (s.eig_sym[id] != 0 && e - c > best_len)
+                    {
+                      best_len = e - c;
+                      best_lo  = c;
+                    }
+                  c = e;
+                }
+              ok            = best_len > 0;
+              f.s7_lo[d]    = best_lo;
+              f.s7_hi[d]    = best_lo + best_len;
+              f.s7_inst[d]  = ok ? s.inst[d][best_lo + 1] : 0;
+            }
+          if (ok)
+            {
+              const int           m = 7, E = m * m + m;
+              std::vector<double> inv((size_t)m * m * m);
+              for (int c = 0; c < m; ++c)
+                for (int b = 0; b < m; ++b)
+                  for (int a = 0; a < m; ++a)
+                    inv[(c * m + b) * m + a] = 1.0 / (s.eig[(size_t)f.s7_inst[0] * E + m * m + a] +
+                                                      (s.eig[(size_t)f.s7_inst[1] * E + m * m + b] + s.eig[(size_t)f.s7_inst[2] * E + m * m + c]));
+              UP(inv, &f.s7_inv);
+              std::vector<int> others;
+              for (int cz = 0; cz < s.g.nc[2]; ++cz)
+                for (int cy = 0; cy < s.g.nc[1]; ++cy)
+                  for (int cx = 0; cx < s.g.nc[0]; ++cx)
+                    if (!(cx >= f.s7_lo[0] && cx < f.s7_hi[0] && cy >= f.s7_lo[1] && cy < f.s7_hi[1] && cz >= f.s7_lo[2] && cz < f.s7_hi[2]))
+                      others.push_back(cx + s.g.nc[0] * (cy + s.g.nc[1] * cz));
+              f.s7_n_others = (int)others.size();
+              f.s7_others   = nullptr;
+              if (!others.empty())
+                {
+                  UP(others, &f.s7_others);
+                }
+              f.s7_on = 1;
+            }
+        }
     }
 #undef UP
   if (alloc_vec(ctx, &ctx->R) || alloc_vec(ctx, &ctx->T) || alloc_vec(ctx, &ctx->S))

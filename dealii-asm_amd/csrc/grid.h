@@ -95,6 +95,13 @@ namespace asmamd
     const double *inv_table;
     const double *w_pre[3];  // [nc[d]][m] 1-D factors of the pre weight, or nullptr
     const double *w_post[3]; // [nc[d]][m] 1-D factors of the post weight, or nullptr
+    // m = 7 on tensor-product meshes: the box of cells [s7_lo, s7_hi) that share one parity-sorted instance per
+    // direction is solved by the slice-per-lane kernel (kernels_slice7.hip), the generic kernel skips it
+    int           s7_on;
+    int           s7_lo[3], s7_hi[3], s7_inst[3];
+    const double *s7_inv;    // [c][b][a] reciprocal eigenvalue sums of that instance triple
+    const int *   s7_others; // the cells outside the box (linear index), for the generic kernel
+    int           s7_n_others;
   };
 
   // geometry + basis of the Laplace operator (device pointers)

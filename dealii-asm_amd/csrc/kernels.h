@@ -20,6 +20,8 @@ namespace asmamd
     double        f1 = 0., f2 = 1.;
   };
   bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, const FdmFused &fu, hipStream_t st);
+  // kernels_slice7.hip: the patch solves of the box f.s7_* into tmp[cell][343] (false: not applicable)
+  bool fdm_slice7(const DevGrid &g, const DevFdm &f, const double *src, double *tmp, hipStream_t st);
   // dst += sign * A src (sign = -1 on a dst initialised with b gives the residual b - A src in one pass)
   bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st, double sign = 1.0);
 

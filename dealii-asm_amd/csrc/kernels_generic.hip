@@ -198,9 +198,12 @@ namespace asmamd
       const int  tid    = threadIdx.x;
       const int  lc     = tid / C::M2;
       const int  lt     = tid % C::M2;
-      const int  ncells = g.nc[0] * g.nc[1] * g.nc[2];
-      const int  cell   = blockIdx.x * C::CPB + lc;
-      const bool active = (lc < C::CPB) && (cell < ncells);
+      const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
+      // M = 7 with a slice-per-lane box (kernels_slice7.hip): this kernel takes the other cells, from a compact list
+      const bool listed = M == 7 && STORE && f.s7_on;
+      const int  slot   = blockIdx.x * C::CPB + lc;
+      const bool active = (lc < C::CPB) && (slot < (listed ? f.s7_n_others : ncells));
+      const int  cell   = active ? (listed ? f.s7_others[slot] : slot) : 0;
 
       int c3[3] = {0, 0, 0}, ids[3] = {0, 0, 0};
       if (active)
@@ -208,6 +211,9 @@ namespace asmamd
           c3[0] = cell % g.nc[0];
           c3[1] = (cell / g.nc[0]) % g.nc[1];
           c3[2] = cell / (g.nc[0] * g.nc[1]);
+        }
+      if (active)
+        {
           // eigen data of the three directions -> LDS
           const int ce = (c3[0] + 1) + (g.nc[0] + 2) * ((c3[1] + 1) + (g.nc[1] + 2) * (c3[2] + 1));
 #pragma unroll
@@ -225,7 +231,7 @@ namespace asmamd
       // Then its matrix is read with scalar loads instead of 49 LDS reads per line.
       int id0[3] = {0, 0, 0}, qmode[3] = {0, 0, 0};
       {
-        const int cell0 = blockIdx.x * C::CPB; // first cell of the block: exists
+        const int cell0 = listed ? f.s7_others[blockIdx.x * C::CPB] : blockIdx.x * C::CPB; // first cell of the block: exists
         const int c0[3] = {cell0 % g.nc[0], (cell0 / g.nc[0]) % g.nc[1], cell0 / (g.nc[0] * g.nc[1])};
         const int ce0   = (c0[0] + 1) + (g.nc[0] + 2) * ((c0[1] + 1) + (g.nc[1] + 2) * (c0[2] + 1));
 #pragma unroll
@@ -824,7 +830,15 @@ namespace asmamd
         hipLaunchKernelGGL((fdm_generic_kernel<M, false>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, dst);
         return;
       }
-    hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, tmp);
+    if (M == 7 && f.s7_on)
+      {
+        const int others = (f.s7_n_others + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
+        if (others > 0)
+          hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(others), dim3(BLOCK), 0, st, g, f, src, tmp);
+        fdm_slice7(g, f, src, tmp, st);
+      }
+    else
+      hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, tmp);
     const long long n = (long long)(g.ext_hi[0] - g.ext_lo[0] + 1) * (g.ext_hi[1] - g.ext_lo[1] + 1) * (g.ext_hi[2] - g.ext_lo[2] + 1);
     const long long gb = std::min<long long>((n + BLOCK - 1) / BLOCK, 1 << 20);
     hipLaunchKernelGGL(fdm_gather_kernel, dim3((unsigned)gb), dim3(BLOCK), 0, st, g, f, fu, src, tmp, dst);

@@ -1,0 +1,269 @@
+// Slice-per-lane patch solve for 7^3 patches (degree 4: n_overlap = 2 and vertex-star) on the region of a
+// tensor-product mesh whose cells share one parity-sorted FDM instance per direction (every cell that is not
+// next to a boundary: 93 % of an 80^3 Dirichlet box, all of a periodic one).
+//
+// It replaces the patch solve of fdm_generic_kernel<7> there (ASPoissonPreconditioner::vmult_internal,
+// include/matrix_free.h:1066-1162, with TensorProductMatrixSymmetricSum::apply_inverse): same inputs, same
+// output (the weighted patch result in tmp[cell][k][j][i], summed per DoF by fdm_gather_kernel), but in the
+// register layout of the tiled 5^3 kernels instead of one thread per line with the tile in LDS:
+//   * 7 lanes per patch, 9 patches (consecutive in x) per wave; a lane holds one 7 x 7 slice of the patch tile in
+//     98 registers: layout A lane = z plane k, v[j*7 + i]; layout B lane = y index, v[k*7 + i];
+//   * the x and y sweeps (layout A) and the z sweep (layout B) are register FMA chains in even-odd form
+//     (16 + 9 products and 6 sums per 7-point line instead of 49 products) with wave-uniform scalar operands;
+//   * two 7-lane transposes through a wave-private LDS buffer; no workgroup barrier anywhere: waves are independent.
+// The generic kernel needs 12 LDS passes over the tile and 6 barriers per patch; this one 2 transposes.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace asmamd
+{
+  namespace
+  {
+    constexpr int M   = 7;
+    constexpr int M2  = 49;
+    constexpr int M3  = 343;
+    constexpr int H   = 3;  // M / 2
+    constexpr int NEV = 4;  // even eigenvectors
+    constexpr int E   = M2 + M; // eigen data per instance
+    constexpr int PPW = 9;  // patches per wave
+    constexpr int WPB = 4;  // waves per workgroup
+    constexpr int TB7 = 64 * M; // doubles of a wave's transpose buffer
+
+    struct UniformMatrix7
+    {
+      const __attribute__((address_space(4))) double *p;
+      __device__ __forceinline__ explicit UniformMatrix7(const double *q)
+        : p((const __attribute__((address_space(4))) double *)q)
+      {}
+      __device__ __forceinline__ double operator[](const int e) const { return p[e]; }
+    };
+
+    // out[a] = sum_i Q[i][a] in[i]; columns 0..3 even, 4..6 odd vectors
+    __device__ __forceinline__ void
+    line7_fwd(double &u0, double &u1, double &u2, double &u3, double &u4, double &u5, double &u6, const UniformMatrix7 &Q)
+    {
+      const double e0 = u0 + u6, e1 = u1 + u5, e2 = u2 + u4, e3 = u3;
+      const double o0 = u0 - u6, o1 = u1 - u5, o2 = u2 - u4;
+      double       t[M];
+#pragma unroll
+      for (int a = 0; a < NEV; ++a)
+        t[a] = fma(Q[3 * M + a], e3, fma(Q[2 * M + a], e2, fma(Q[1 * M + a], e1, Q[0 * M + a] * e0)));
+#pragma unroll
+      for (int a = NEV; a < M; ++a)
+        t[a] = fma(Q[2 * M + a], o2, fma(Q[1 * M + a], o1, Q[0 * M + a] * o0));
+      u0 = t[0];
+      u1 = t[1];
+      u2 = t[2];
+      u3 = t[3];
+      u4 = t[4];
+      u5 = t[5];
+      u6 = t[6];
+    }
+    // out[i] = sum_a Q[i][a] in[a]
+    __device__ __forceinline__ void
+    line7_bwd(double &u0, double &u1, double &u2, double &u3, double &u4, double &u5, double &u6, const UniformMatrix7 &Q)
+    {
+      double Ev[NEV], Od[H];
+#pragma unroll
+      for (int i = 0; i < NEV; ++i)
+        Ev[i] = fma(Q[i * M + 3], u3, fma(Q[i * M + 2], u2, fma(Q[i * M + 1], u1, Q[i * M + 0] * u0)));
+#pragma unroll
+      for (int i = 0; i < H; ++i)
+        Od[i] = fma(Q[i * M + 6], u6, fma(Q[i * M + 5], u5, Q[i * M + 4] * u4));
+      u0 = Ev[0] + Od[0];
+      u6 = Ev[0] - Od[0];
+      u1 = Ev[1] + Od[1];
+      u5 = Ev[1] - Od[1];
+      u2 = Ev[2] + Od[2];
+      u4 = Ev[2] - Od[2];
+      u3 = Ev[3];
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void
+    sweep_fast7(double (&v)[M2], const UniformMatrix7 &Q)
+    {
+#pragma unroll
+      for (int s = 0; s < M; ++s)
+        {
+          if (FWD)
+            line7_fwd(v[s * M + 0], v[s * M + 1], v[s * M + 2], v[s * M + 3], v[s * M + 4], v[s * M + 5], v[s * M + 6], Q);
+          else
+            line7_bwd(v[s * M + 0], v[s * M + 1], v[s * M + 2], v[s * M + 3], v[s * M + 4], v[s * M + 5], v[s * M + 6], Q);
+        }
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void
+    sweep_slow7(double (&v)[M2], const UniformMatrix7 &Q)
+    {
+#pragma unroll
+      for (int f = 0; f < M; ++f)
+        {
+          if (FWD)
+            line7_fwd(v[0 * M + f], v[1 * M + f], v[2 * M + f], v[3 * M + f], v[4 * M + f], v[5 * M + f], v[6 * M + f], Q);
+          else
+            line7_bwd(v[0 * M + f], v[1 * M + f], v[2 * M + f], v[3 * M + f], v[4 * M + f], v[5 * M + f], v[6 * M + f], Q);
+        }
+    }
+
+    // 7-lane transpose: lane `sub` of a patch holds v[s*7 + f]; afterwards v'[s*7 + f] = (v[sub*7 + f] of the patch's lane s).
+    // The LDS executes a wave's accesses in order: no wait between the rounds (see transpose5 in kernels_tiled.hip).
+    __device__ __forceinline__ void
+    transpose7(double (&v)[M2], double *__restrict__ Tw, const int lane, const int cl, const int sub)
+    {
+#pragma unroll
+      for (int f = 0; f < M; ++f)
+        {
+#pragma unroll
+          for (int s = 0; s < M; ++s)
+            Tw[lane * M + s] = v[s * M + f];
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int s = 0; s < M; ++s)
+            v[s * M + f] = Tw[(cl * M + s) * M + sub];
+          asm volatile("" ::: "memory");
+        }
+    }
+
+    struct Slice7Args
+    {
+      int           lo[3], n[3];  // region of cells [lo, lo + n)
+      int           npx;          // waves along x
+      const double *qx, *qy, *qz; // the region's eigenvector matrices (E doubles each)
+      const double *inv;          // [c][b][a] reciprocal eigenvalue sums of the region's instance triple
+    };
+
+    template <bool HAS_PRE, bool HAS_POST>
+    __global__ void __launch_bounds__(WPB * 64)
+    fdm_slice7_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const double *__restrict__ src, double *__restrict__ tmp)
+    {
+      __shared__ double S_T[WPB * TB7];
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      const long long gw = (long long)blockIdx.x * WPB + w; // wave index: (px, cy, cz)
+      const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
+      if (gw >= n_waves)
+        return; // no barrier in this kernel
+      const int px = (int)(gw % sa.npx), cy = sa.lo[1] + (int)((gw / sa.npx) % sa.n[1]), cz = sa.lo[2] + (int)(gw / ((long long)sa.npx * sa.n[1]));
+      int       cl = lane / M;
+      const int sub = lane - cl * M;
+      int       cx  = sa.lo[0] + px * PPW + cl;
+      // lanes without a patch (lane 63, patches beyond the region) run along on the last valid patch and store nothing
+      const bool active = cl < PPW && cx < sa.lo[0] + sa.n[0];
+      if (!active)
+        cx = sa.lo[0] + sa.n[0] - 1;
+      double *Tw = S_T + w * TB7;
+
+      const int o0 = f.origin_mul * cx + f.origin_add, o1 = f.origin_mul * cy + f.origin_add, o2 = f.origin_mul * cz + f.origin_add;
+      // every DoF of a region patch exists (the region's cells have both neighbours in every direction)
+      const long long zoff = g.store_index_near(2, o2 + sub) * g.stride[2];
+      const int       x0   = g.store_index_near(0, o0);
+      const bool      xcont = g.store_index_near(0, o0 + M - 1) == x0 + M - 1; // no periodic seam inside the row
+
+      double v[M2];
+      // ---- gather: layout A, lane = z plane `sub`, v[j*7 + i]
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        {
+          const double *row = src + zoff + g.store_index_near(1, o1 + j) * g.stride[1];
+          if (xcont)
+            {
+#pragma unroll
+              for (int i = 0; i < M; ++i)
+                v[j * M + i] = row[x0 + i];
+            }
+          else
+            {
+#pragma unroll
+              for (int i = 0; i < M; ++i)
+                v[j * M + i] = row[g.store_index_near(0, o0 + i)];
+            }
+        }
+      if (HAS_PRE)
+        {
+          const double wz = f.w_pre[2][(cz + 1) * M + sub];
+          double       wx[M];
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+            wx[i] = f.w_pre[0][(cx + 1) * M + i];
+#pragma unroll
+          for (int j = 0; j < M; ++j)
+            {
+              const double wyz = f.w_pre[1][(cy + 1) * M + j] * wz;
+#pragma unroll
+              for (int i = 0; i < M; ++i)
+                v[j * M + i] *= wx[i] * wyz;
+            }
+        }
+      const UniformMatrix7 Qx(sa.qx), Qy(sa.qy), Qz(sa.qz);
+      sweep_fast7<true>(v, Qx);  // i -> a
+      sweep_slow7<true>(v, Qy);  // j -> b
+      transpose7(v, Tw, lane, cl, sub); // layout B: lane = b, v[k*7 + a]
+      sweep_slow7<true>(v, Qz);  // k -> c
+      {
+        const double *inv = sa.inv + sub * M; // [c][b = sub][a]
+#pragma unroll
+        for (int c = 0; c < M; ++c)
+#pragma unroll
+          for (int a = 0; a < M; ++a)
+            v[c * M + a] *= inv[c * M2 + a];
+      }
+      sweep_slow7<false>(v, Qz);
+      transpose7(v, Tw, lane, cl, sub); // layout A: lane = k, v[b*7 + a]
+      sweep_slow7<false>(v, Qy);
+      sweep_fast7<false>(v, Qx);
+      if (HAS_POST)
+        {
+          const double wz = f.w_post[2][(cz + 1) * M + sub];
+          double       wx[M];
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+            wx[i] = f.w_post[0][(cx + 1) * M + i];
+#pragma unroll
+          for (int j = 0; j < M; ++j)
+            {
+              const double wyz = f.w_post[1][(cy + 1) * M + j] * wz;
+#pragma unroll
+              for (int i = 0; i < M; ++i)
+                v[j * M + i] *= wx[i] * wyz;
+            }
+        }
+      if (active)
+        {
+          const long long cell = cx + (long long)g.nc[0] * (cy + (long long)g.nc[1] * cz);
+          double *        out  = tmp + cell * M3 + sub * M2;
+#pragma unroll
+          for (int e = 0; e < M2; ++e)
+            out[e] = v[e];
+        }
+    }
+  } // namespace
+
+  bool
+  fdm_slice7(const DevGrid &g, const DevFdm &f, const double *src, double *tmp, hipStream_t st)
+  {
+    if (!f.s7_on || f.m != M)
+      return false;
+    Slice7Args sa;
+    for (int d = 0; d < 3; ++d)
+      {
+        sa.lo[d] = f.s7_lo[d];
+        sa.n[d]  = f.s7_hi[d] - f.s7_lo[d];
+      }
+    sa.npx = (sa.n[0] + PPW - 1) / PPW;
+    sa.qx  = f.eig + (long long)f.s7_inst[0] * E;
+    sa.qy  = f.eig + (long long)f.s7_inst[1] * E;
+    sa.qz  = f.eig + (long long)f.s7_inst[2] * E;
+    sa.inv = f.s7_inv;
+    const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
+    const unsigned  blocks  = (unsigned)((n_waves + WPB - 1) / WPB);
+    if (f.has_pre && f.has_post)
+      hipLaunchKernelGGL((fdm_slice7_kernel<true, true>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+    else if (f.has_pre)
+      hipLaunchKernelGGL((fdm_slice7_kernel<true, false>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+    else if (f.has_post)
+      hipLaunchKernelGGL((fdm_slice7_kernel<false, true>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+    else
+      hipLaunchKernelGGL((fdm_slice7_kernel<false, false>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+    return true;
+  }
+} // namespace asmamd
