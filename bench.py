@@ -144,6 +144,11 @@ def main():
         args.gpus = world
 
     pkg = load_package()
+    # the library (and with it the system's HIP runtime and RCCL it links) is loaded before torch, so that the
+    # process has ONE HIP runtime and ONE RCCL, the ones the kernels were built against, whatever torch bundles
+    # (ASM_BENCH_TORCH_FIRST=1: the other order - torch's bundled libamdhip64 / librccl then serve the library too)
+    if not os.environ.get("ASM_BENCH_TORCH_FIRST"):
+        pkg.load_library()
     dist = None
     if world > 1:
         # The process group only bootstraps the library's own RCCL communicator (broadcast of the
