@@ -1097,10 +1097,6 @@ asm_create(const asm_params *p, asm_ctx **out)
   UP(ctx->basis->Dc, &op.Dc);
   UP(ctx->basis->xq, &op.xq);
   UP(ctx->basis->wq, &op.wq);
-  UP(ctx->basis->M_ref, &op.M_ref);
-  UP(ctx->basis->K_ref, &op.K_ref);
-  UP(ctx->basis->M_eo, &op.M_eo);
-  UP(ctx->basis->K_eo, &op.K_eo);
   if (ctx->basis->n1 == 5)
     ctx->basis->diagonalise();
   UP(ctx->basis->F_ref, &op.F_ref);

@@ -114,10 +114,6 @@ namespace asmamd
     const double *Dc;     // [q][r]
     const double *xq;     // [q]
     const double *wq;     // [q]
-    const double *M_ref;  // [i][j] reference mass matrix of FE_Q<1>(p) on [0,1]
-    const double *K_ref;  // [i][j] reference stiffness matrix
-    const double *M_eo;   // degree 4: even-odd coefficients of M_ref / K_ref (numerics.h: even_odd_coefficients)
-    const double *K_eo;
     // degree 4: M_ref = F F^T, K_ref = F diag(lam) F^T with parity-sorted columns of F (numerics.h: Basis1D::diagonalise)
     const double *F_ref;   // [i][a]
     const double *lam_ref; // [a]

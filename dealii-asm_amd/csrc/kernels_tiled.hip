@@ -37,11 +37,6 @@
 
 namespace asmamd
 {
-  bool
-  tiled_kernels_available()
-  {
-    return true;
-  }
 #ifdef ASM_STAMP
   void tiled_debug_stamps(unsigned long long out[32], bool reset);
 #endif

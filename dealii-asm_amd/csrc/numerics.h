@@ -147,19 +147,6 @@ namespace asmamd
     return ab < cd ? ab : cd;
   }
 
-  // Even-odd form of y = A u for a 5 x 5 matrix that is symmetric and invariant under
-  // (i, j) -> (4-i, 4-j): with e0 = u0+u4, e1 = u1+u3, m = u2, o0 = u0-u4, o1 = u1-u3,
-  //   S0 = c0 e0 + c1 e1 + c2 m,  S1 = c1 e0 + c3 e1 + c4 m,  y2 = c2 e0 + c4 e1 + c5 m,
-  //   D0 = c6 o0 + c7 o1,         D1 = c7 o0 + c8 o1,
-  //   y0 = S0 + D0, y4 = S0 - D0, y1 = S1 + D1, y3 = S1 - D1      (13 products instead of 25)
-  inline std::vector<double>
-  even_odd_coefficients(const std::vector<double> &A)
-  {
-    const auto a = [&](const int i, const int j) { return A[i * 5 + j]; };
-    return {0.5 * (a(0, 0) + a(0, 4)), 0.5 * (a(0, 1) + a(0, 3)), a(0, 2), 0.5 * (a(1, 1) + a(1, 3)), a(1, 2), a(2, 2),
-            0.5 * (a(0, 0) - a(0, 4)), 0.5 * (a(0, 1) - a(0, 3)), 0.5 * (a(1, 1) - a(1, 3))};
-  }
-
   // Eigenvectors of a pencil that is invariant under the reflection i -> m-1-i are even or odd
   // vectors.  If that is the case for Q[i*m + a] (m odd), reorder the eigenpairs so that the
   // (m+1)/2 even vectors come first, make the symmetry hold bitwise, and return true: kernels may
@@ -218,8 +205,6 @@ namespace asmamd
     std::vector<double> Dc; // [q][r] collocation derivative: d/dx of the Lagrange
                             // basis ON the quadrature points, at those points
     std::vector<double> M_ref, K_ref; // [i][j]
-    // degree 4: the 9 coefficients of the even-odd form of M_ref / K_ref (see even_odd_coefficients)
-    std::vector<double> M_eo, K_eo;
     // simultaneous diagonalisation of the reference matrices (filled by Basis1D::diagonalise, which
     // needs generalized_eigen): K_ref Q = M_ref Q diag(lam), Q^T M_ref Q = I, eigenvectors sorted by
     // parity; F = M_ref Q (row i, column a), so that  M_ref = F F^T  and  K_ref = F diag(lam) F^T
@@ -259,11 +244,6 @@ namespace asmamd
             M_ref[i * n1 + j] = M_ref[e];
             K_ref[i * n1 + j] = K_ref[e];
           }
-      if (n1 == 5)
-        {
-          M_eo = even_odd_coefficients(M_ref);
-          K_eo = even_odd_coefficients(K_ref);
-        }
     }
   };
 

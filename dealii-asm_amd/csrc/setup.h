@@ -32,9 +32,6 @@ namespace asmamd
     FACE_WRAP      = 4  // periodic, single rank in this direction
   };
 
-  // defined next to the tiled kernels (kernels_tiled.hip)
-  bool tiled_kernels_available();
-
   inline int
   imod(int a, const int n)
   {
@@ -258,7 +255,7 @@ namespace asmamd
     const bool fdm_ok = (!vertex && prm.n_overlap == 1 && p == 4), laplace_ok = (p == 4 && prm.geometry == ASM_GEOM_CARTESIAN);
     const bool tiled_ok = fdm_ok || laplace_ok;
     if (s.kernel == ASM_KERNEL_AUTO)
-      s.kernel = (tiled_ok && tiled_kernels_available()) ? ASM_KERNEL_TILED : ASM_KERNEL_GENERIC;
+      s.kernel = tiled_ok ? ASM_KERNEL_TILED : ASM_KERNEL_GENERIC;
     if (s.kernel == ASM_KERNEL_TILED && !tiled_ok)
       {
         s.error = "tiled kernels exist for degree 4 only: FDM for n_overlap 1 element-centric patches, Laplace for Cartesian cells";
