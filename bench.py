@@ -197,6 +197,12 @@ def main():
         # the timed loop modifies its vectors through the library only: the exchange of a step's result
         # (overlapped with the sweep that produces it) then serves the next step, as asm_set_keep_ghosts documents
         ctx.set_keep_ghosts(True)
+    self_interface = world == 1 and os.environ.get("ASM_SELF_INTERFACE") and args.workload == "cart_periodic"
+    if self_interface:
+        # rehearsal of the multi-rank path on one GPU (tests/test_gpu_rccl_self.py): the rank exchanges its 26 ghost
+        # messages with itself through RCCL; not a bench configuration, the line says so
+        ctx.comm_init(pkg.comm_unique_id())
+        ctx.set_keep_ghosts(True)
 
     def barrier():
         # the library's two streams (sweeps, ghost exchange) carry all GPU work of this process:
@@ -295,6 +301,7 @@ def main():
                 "proc_grid": grid,
                 "kernel_variant": ctx.kernel_variant(),
                 "lambda_max_estimate": lam,
+                **({"rehearsal": "periodic directions closed by RCCL messages of the rank to itself"} if self_interface else {}),
             },
             "application_bytes_per_dof": (sum(a_sw) + sum(p_sw)),
             "application_hbm_frac": total_bytes / world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,

@@ -72,6 +72,7 @@ struct asm_ctx
   DevFdm                   f;
   DevOp                    op;
   std::vector<void *>      allocs;
+  std::vector<double *>    work_pool; // released solver work vectors (asm_work_vector_*), kept until asm_destroy
   long long                data_bytes = 0;
   double *                 inv_diag   = nullptr;
   double *                 R = nullptr, *T = nullptr, *S = nullptr; // scratch vectors
@@ -96,7 +97,8 @@ struct asm_ctx
   // exchange of the NEW vector then runs on comm_stream beside the remaining workgroups, and the next
   // sweep only waits for ev_exchanged.
   hipStream_t              comm_stream  = nullptr;
-  hipEvent_t               ev_boundary  = nullptr, ev_exchanged = nullptr;
+  hipStream_t              bnd_stream   = nullptr; // boundary workgroups of an overlapped sweep (high priority)
+  hipEvent_t               ev_boundary  = nullptr, ev_exchanged = nullptr, ev_start = nullptr;
   bool                     overlap      = false;   // available (set by asm_comm_init)
   bool                     in_cheb      = false;   // inside cheb_run
   bool                     last_sweep   = false;   // the sweep's result is not read by another sweep of this call
@@ -204,7 +206,7 @@ namespace
   bool
   multi_rank(const asm_ctx *ctx)
   {
-    return ctx->s.prm.world_size > 1;
+    return ctx->s.prm.world_size > 1 || ctx->s.self_interface;
   }
 
   // kernel ids: 0 = Laplace sweep kernel, 1 = FDM sweep kernel
@@ -480,25 +482,43 @@ namespace
     if (!ov && ctx->debug_two_phase)
       {
         a.phase = 1;
-        *ok     = launch(a);
+        *ok     = launch(a, ctx->stream);
         a.phase = 2;
-        *ok     = *ok && launch(a);
+        *ok     = *ok && launch(a, ctx->stream);
         return ASM_OK;
       }
     if (!ov)
       {
         a.phase = 0;
-        *ok     = launch(a);
+        *ok     = launch(a, ctx->stream);
         return ASM_OK;
       }
+    if (ctx->bnd_stream == nullptr)
+      {
+        // the boundary workgroups (padded to whole rounds of compute units), then the others, on one stream
+        a.phase = 1;
+        *ok     = launch(a, ctx->stream);
+        if (!*ok)
+          return ASM_OK;
+        HIP_TRY(hipEventRecord(ctx->ev_boundary, ctx->stream));
+        a.phase = 2;
+        *ok     = launch(a, ctx->stream);
+        // enqueued behind the interior launch on the host, beside it on the device
+        return exchange_overlapped(ctx, a.dst);
+      }
+    // Boundary workgroups on a high-priority stream, the interior ones beside them on the main stream: the boundary
+    // launch does not leave compute units idle while its last workgroups finish, and the exchange starts as soon as
+    // the boundary workgroups (dispatched first) are through.
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->bnd_stream, ctx->ev_start, 0));
     a.phase = 1;
-    *ok     = launch(a);
+    *ok     = launch(a, ctx->bnd_stream);
     if (!*ok)
       return ASM_OK;
-    HIP_TRY(hipEventRecord(ctx->ev_boundary, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_boundary, ctx->bnd_stream));
     a.phase = 2;
-    *ok     = launch(a);
-    // enqueued behind the interior launch on the host, beside it on the device
+    *ok     = launch(a, ctx->stream);
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_boundary, 0)); // the sweep is complete on the main stream
     return exchange_overlapped(ctx, a.dst);
   }
 
@@ -518,7 +538,7 @@ namespace
         TiledArgs a{mode, src, dst, b, nullptr, nullptr, 0., 0.};
         prof_mark(ctx, 0, true);
         bool ok = false;
-        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t) { return laplace_tiled(ctx->g, ctx->op, t, ctx->stream); }, &ok);
+        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t, hipStream_t st) { return laplace_tiled(ctx->g, ctx->op, t, st); }, &ok);
         if (err)
           return err;
         if (ok)
@@ -593,7 +613,7 @@ namespace
         TiledArgs a{mode, src, dst, nullptr, x, x_old, f1, f2};
         prof_mark(ctx, 1, true);
         bool ok = false;
-        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t) { return fdm_tiled(ctx->g, ctx->f, t, ctx->stream); }, &ok);
+        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t, hipStream_t st) { return fdm_tiled(ctx->g, ctx->f, t, st); }, &ok);
         if (err)
           return err;
         prof_mark(ctx, 1, false);
@@ -1101,9 +1121,21 @@ asm_create(const asm_params *p, asm_ctx **out)
     ctx->basis->diagonalise();
   UP(ctx->basis->F_ref, &op.F_ref);
   UP(ctx->basis->lam_ref, &op.lam_ref);
+  // low-order levels (the bottom of a multigrid hierarchy): one thread per cell (ASM_NO_SMALL keeps the generic sweeps)
+  const bool small_sweeps = std::getenv("ASM_NO_SMALL") == nullptr;
+  op.small                = small_sweeps && s.cartesian && s.g.p <= 2;
+  for (int q = 0; q < 9; ++q)
+    op.M_small[q] = op.K_small[q] = 0.;
+  if (op.small)
+    for (int q = 0; q < ctx->basis->n1 * ctx->basis->n1; ++q)
+      {
+        op.M_small[q] = ctx->basis->M_ref[q];
+        op.K_small[q] = ctx->basis->K_ref[q];
+      }
   // FDM data
   DevFdm &f = ctx->f;
   std::memset(&f, 0, sizeof(f));
+  f.small       = small_sweeps && s.m <= 3;
   f.m           = s.m;
   const bool vx = s.prm.element_centric == 0;
   f.origin_mul  = s.g.p;
@@ -1302,6 +1334,12 @@ asm_destroy(asm_ctx *ctx)
       (void)hipEventDestroy(ctx->ev_boundary);
       (void)hipEventDestroy(ctx->ev_exchanged);
       (void)hipStreamDestroy(ctx->comm_stream);
+      if (ctx->bnd_stream)
+        {
+          (void)hipStreamSynchronize(ctx->bnd_stream);
+          (void)hipEventDestroy(ctx->ev_start);
+          (void)hipStreamDestroy(ctx->bnd_stream);
+        }
     }
   if (ctx->comm)
     ncclCommDestroy(ctx->comm);
@@ -1312,6 +1350,8 @@ asm_destroy(asm_ctx *ctx)
         (void)hipEventDestroy(e.second);
       }
   for (void *q : ctx->allocs)
+    (void)hipFree(q);
+  for (double *q : ctx->work_pool)
     (void)hipFree(q);
   if (ctx->h_scalar)
     (void)hipHostFree(ctx->h_scalar);
@@ -1337,6 +1377,13 @@ setup_overlap(asm_ctx *ctx)
       HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&ctx->ev_boundary, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&ctx->ev_exchanged, hipEventDisableTiming));
+      if (std::getenv("ASM_CONCURRENT_PHASES") != nullptr) // experiments: measured slower (cross-queue waits, profiles/r02_multirank_rehearsal.txt)
+        {
+          int lo = 0, hi = 0; // (numerically lower = higher priority)
+          HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+          HIP_TRY(hipStreamCreateWithPriority(&ctx->bnd_stream, hipStreamNonBlocking, hi));
+          HIP_TRY(hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming));
+        }
       ctx->overlap = true;
     }
   return ASM_OK;
@@ -1374,7 +1421,7 @@ asm_comm_init(asm_ctx *ctx, const char id[128])
       g_create_error = "asm_comm_init: context and unique id must be given";
       return ASM_ERR_INVALID_VALUE;
     }
-  if (ctx->s.prm.world_size < 2)
+  if (!multi_rank(ctx))
     {
       ctx->error = "asm_comm_init: the context was created for a single rank (world_size = 1)";
       return ASM_ERR_INVALID_VALUE;
@@ -1420,6 +1467,30 @@ asm_vector_free(asm_ctx *ctx, double *v)
     ctx->exchanged_vec = nullptr;
   HIP_TRY(hipFree(v));
   return ASM_OK;
+}
+
+// Work vectors of the Krylov solvers (multigrid.hip): taken from / returned to a per-context pool, as deal.II's
+// GrowingVectorMemory does for SolverGMRES / SolverCG, so that a repeated solve does not allocate.
+int
+asm_work_vector_acquire(asm_ctx *ctx, double **v)
+{
+  const DeviceScope device_scope(ctx);
+  if (!ctx->work_pool.empty())
+    {
+      *v = ctx->work_pool.back();
+      ctx->work_pool.pop_back();
+      HIP_TRY(hipMemsetAsync(*v, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+      return ASM_OK;
+    }
+  return alloc_vec(ctx, v);
+}
+
+void
+asm_work_vector_release(asm_ctx *ctx, double *v)
+{
+  if (v == ctx->exchanged_vec)
+    ctx->exchanged_vec = nullptr;
+  ctx->work_pool.push_back(v);
 }
 
 int

@@ -102,6 +102,7 @@ namespace asmamd
     const double *s7_inv;    // [c][b][a] reciprocal eigenvalue sums of that instance triple
     const int *   s7_others; // the cells outside the box (linear index), for the generic kernel
     int           s7_n_others;
+    int           small;     // m <= 3: one thread per cell, the patch in registers (kernels_small.hip)
   };
 
   // geometry + basis of the Laplace operator (device pointers)
@@ -117,5 +118,9 @@ namespace asmamd
     // degree 4: M_ref = F F^T, K_ref = F diag(lam) F^T with parity-sorted columns of F (numerics.h: Basis1D::diagonalise)
     const double *F_ref;   // [i][a]
     const double *lam_ref; // [a]
+    // degree <= 2 on Cartesian cells: one thread per cell with the 1-D reference mass and stiffness matrices
+    // ([i][j], row length p + 1) as kernel arguments (kernels_small.hip)
+    int    small;
+    double M_small[9], K_small[9];
   };
 } // namespace asmamd

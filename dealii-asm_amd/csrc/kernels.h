@@ -25,6 +25,11 @@ namespace asmamd
   // dst += sign * A src (sign = -1 on a dst initialised with b gives the residual b - A src in one pass)
   bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st, double sign = 1.0);
 
+  // ---- low-order sweeps, one thread per cell (kernels_small.hip); same contracts as fdm_generic's solve stage
+  //      (store: dst = tmp[cell][m^3]; otherwise atomics on dst) and laplace_generic; false: not applicable
+  bool fdm_cell(const DevGrid &g, const DevFdm &f, const double *src, double *dst, bool store, hipStream_t st);
+  bool laplace_cell(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st, double sign);
+
   // ---- tiled owner-computes sweeps (kernels_tiled.hip), degree 4, n_overlap 1
   enum TiledMode
   {

@@ -827,10 +827,13 @@ namespace asmamd
     const int blocks = (ncells + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
     if (tmp == nullptr)
       {
-        hipLaunchKernelGGL((fdm_generic_kernel<M, false>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, dst);
+        if (!(M <= 3 && f.small && fdm_cell(g, f, src, dst, false, st)))
+          hipLaunchKernelGGL((fdm_generic_kernel<M, false>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, dst);
         return;
       }
-    if (M == 7 && f.s7_on)
+    if (M <= 3 && f.small && fdm_cell(g, f, src, tmp, true, st))
+      ;
+    else if (M == 7 && f.s7_on)
       {
         const int others = (f.s7_n_others + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
         if (others > 0)
@@ -878,6 +881,8 @@ namespace asmamd
   bool
   laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st, const double sign)
   {
+    if (op.small && laplace_cell(g, op, src, dst, diag, st, sign))
+      return true;
 #define ASM_CASE(P)                              \
   case P:                                        \
     if (diag)                                    \

@@ -122,6 +122,13 @@ namespace asmamd
     {
       int ntx, nty, nzc; // tiles in x, y; chunks in z
       int zlen;          // owned cell layers per chunk
+      // Two-phase launches (TiledArgs::phase 1 / 2): the workgroups in "phase order": the boundary ones (up to six
+      // slabs around the box of interior workgroups) first, then the interior box, each box in lexicographic order.
+      // Phase 1 is the first n_first of them (all boundary workgroups, padded with interior ones to whole rounds of
+      // compute units), phase 2 the others; each phase is a dense launch, so that its workgroups spread evenly over
+      // the XCDs whatever the shape of the boundary set.
+      int n_box, box_lo[7][3], box_size[7][3], box_end[7]; // box_end: cumulative workgroup counts
+      int n_first;
     };
 
     // Workgroups b and b + 8 are observed to land on the same XCD (same L2).  Give the
@@ -135,15 +142,25 @@ namespace asmamd
       return xcd * (n >> 3) + min(xcd, n & 7) + idx;
     }
 
-    // does this workgroup take part in the launch (TiledArgs::phase)?
-    __device__ __forceinline__ bool
-    workgroup_in_phase(const TiledArgs &a, const Tiling &tl, const int tx, const int ty, const int zc)
+    // workgroup (tile x, tile y, z chunk) of this block
+    __device__ __forceinline__ void
+    workgroup_of_block(const TiledArgs &a, const Tiling &tl, int &tx, int &ty, int &zc)
     {
+      const int i = xcd_remap(blockIdx.x, gridDim.x);
       if (a.phase == 0)
-        return true;
-      const bool bnd = (a.iface[0][0] && tx == 0) || (a.iface[0][1] && tx == tl.ntx - 1) || (a.iface[1][0] && ty == 0) ||
-                       (a.iface[1][1] && ty == tl.nty - 1) || (a.iface[2][0] && zc == 0) || (a.iface[2][1] && zc == tl.nzc - 1);
-      return (a.phase == 1) == bnd;
+        {
+          tx = i % tl.ntx;
+          ty = (i / tl.ntx) % tl.nty;
+          zc = i / (tl.ntx * tl.nty);
+          return;
+        }
+      int o = i + (a.phase == 2 ? tl.n_first : 0), k = 0, begin = 0;
+      while (k + 1 < tl.n_box && o >= tl.box_end[k])
+        begin = tl.box_end[k++];
+      o -= begin;
+      tx = tl.box_lo[k][0] + o % tl.box_size[k][0];
+      ty = tl.box_lo[k][1] + (o / tl.box_size[k][0]) % tl.box_size[k][1];
+      zc = tl.box_lo[k][2] + o / (tl.box_size[k][0] * tl.box_size[k][1]);
     }
 
     // is cell c (local coordinate, may be -1) computed by this rank?
@@ -956,10 +973,8 @@ namespace asmamd
       double *S_G   = S_Y + LDS_Y;
       double *S_tab = S_G + LDS_G;
 
-      const int b  = xcd_remap(blockIdx.x, gridDim.x);
-      const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
-      if (!workgroup_in_phase(a, tl, tx, ty, zc))
-        return;
+      int tx, ty, zc;
+      workgroup_of_block(a, tl, tx, ty, zc);
       const int X0 = tx * OX - 1, Y0 = ty * OY - 1; // tile cell (0,0)
 
       CellLane c;
@@ -1252,10 +1267,8 @@ namespace asmamd
       double *S_Y = S_T + LDS_T;
       double *S_G = S_Y + LDS_Y;
 
-      const int b  = xcd_remap(blockIdx.x, gridDim.x);
-      const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
-      if (!workgroup_in_phase(a, tl, tx, ty, zc))
-        return;
+      int tx, ty, zc;
+      workgroup_of_block(a, tl, tx, ty, zc);
       const int X0 = tx * OX - 1, Y0 = ty * OY - 1;
 
       CellLane c;
@@ -1384,10 +1397,8 @@ namespace asmamd
       double *S_Y = S_T + T2::L_T;
       double *S_G = S_Y + T2::L_Y;
 
-      const int b  = xcd_remap(blockIdx.x, gridDim.x);
-      const int tx = b % tl.ntx, ty = (b / tl.ntx) % tl.nty, zc = b / (tl.ntx * tl.nty);
-      if (!workgroup_in_phase(a, tl, tx, ty, zc))
-        return;
+      int tx, ty, zc;
+      workgroup_of_block(a, tl, tx, ty, zc);
       const int X0 = tx * OX - 1, Y0 = ty * T2::OYW - 1;
 
       CellLane c;
@@ -1472,11 +1483,13 @@ namespace asmamd
 
 
     Tiling
-    make_tiling(const DevGrid &g, int n_cu, const int oy = OY)
+    make_tiling(const DevGrid &g, const TiledArgs &a, const int oy = OY)
     {
+      int    n_cu = a.n_cu;
       Tiling tl;
       tl.ntx = (g.nc[0] + OX - 1) / OX;
       tl.nty = (g.nc[1] + oy - 1) / oy;
+      tl.n_box = tl.n_first = 0;
       // the last owned plane nc*p of a non-wrapped direction is produced by the tile
       // that holds cell nc-1, no extra tile needed
       const int tiles = tl.ntx * tl.nty;
@@ -1499,12 +1512,80 @@ namespace asmamd
               best      = nzc;
             }
         }
+      // Two-phase launch (ghost exchange of the result overlapped with phase 2): phase 1 = the workgroups that produce
+      // what neighbours ghost, padded with interior ones to whole rounds; the exchange (about x_layers layer times)
+      // has phase 2 to hide in.  More, shorter chunks make phase 1 short when the z faces are interfaces.
+      const auto phases = [&](const int chunks, int &n_first, int &n_int_total) {
+        const int ix = tl.ntx - (a.iface[0][0] ? 1 : 0) - (a.iface[0][1] ? 1 : 0), iy = tl.nty - (a.iface[1][0] ? 1 : 0) - (a.iface[1][1] ? 1 : 0),
+                  iz = chunks - (a.iface[2][0] ? 1 : 0) - (a.iface[2][1] ? 1 : 0);
+        n_int_total  = std::max(ix, 0) * std::max(iy, 0) * std::max(iz, 0);
+        const int nb = tiles * chunks - n_int_total;
+        n_first      = std::min(tiles * chunks, (nb + n_cu - 1) / n_cu * n_cu);
+      };
+      if (a.phase != 0)
+        {
+          static const double x_layers = std::getenv("ASM_EXCHANGE_LAYERS") ? std::atof(std::getenv("ASM_EXCHANGE_LAYERS")) : 20.;
+          best_cost                    = 1e300;
+          for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
+            {
+              const int zlen = (g.nc[2] + nzc - 1) / nzc, chunks = (g.nc[2] + zlen - 1) / zlen;
+              int       n_first, n_int;
+              phases(chunks, n_first, n_int);
+              const double L    = zlen + 1.5;
+              const double cost = (n_first + n_cu - 1) / n_cu * L + std::max((tiles * chunks - n_first + n_cu - 1) / n_cu * L, x_layers);
+              if (cost < best_cost - 1e-9)
+                {
+                  best_cost = cost;
+                  best      = nzc;
+                }
+            }
+        }
       static const int forced = std::getenv("ASM_TILED_ZCHUNKS") ? std::atoi(std::getenv("ASM_TILED_ZCHUNKS")) : 0; // experiments only
       if (forced > 0)
         best = std::min(forced, g.nc[2]);
       tl.zlen = (g.nc[2] + best - 1) / best;
       tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
+      if (a.phase != 0)
+        {
+          int n_first, n_int;
+          phases(tl.nzc, n_first, n_int);
+          tl.n_first = n_first;
+          const int n[3]  = {tl.ntx, tl.nty, tl.nzc};
+          int       lo[3] = {0, 0, 0}, hi[3] = {n[0], n[1], n[2]}; // what is left of the box after the slabs taken so far
+          const auto add = [&](const int blo[3], const int bhi[3]) {
+            const int sz[3] = {bhi[0] - blo[0], bhi[1] - blo[1], bhi[2] - blo[2]};
+            if (sz[0] <= 0 || sz[1] <= 0 || sz[2] <= 0)
+              return;
+            const int k = tl.n_box++;
+            for (int d = 0; d < 3; ++d)
+              {
+                tl.box_lo[k][d]   = blo[d];
+                tl.box_size[k][d] = sz[d];
+              }
+            tl.box_end[k] = (k ? tl.box_end[k - 1] : 0) + sz[0] * sz[1] * sz[2];
+          };
+          for (int d = 2; d >= 0; --d) // slabs: z low / high, then y, then x
+            for (int f = 0; f < 2; ++f)
+              if (a.iface[d][f] && hi[d] > lo[d])
+                {
+                  int blo[3] = {lo[0], lo[1], lo[2]}, bhi[3] = {hi[0], hi[1], hi[2]};
+                  if (f == 0)
+                    bhi[d] = ++lo[d];
+                  else
+                    blo[d] = --hi[d];
+                  add(blo, bhi);
+                }
+          add(lo, hi); // the interior
+        }
       return tl;
+    }
+
+    // blocks of a launch (0: nothing to do in this phase)
+    int
+    blocks_of_phase(const Tiling &tl, const TiledArgs &a)
+    {
+      const int total = tl.ntx * tl.nty * tl.nzc;
+      return a.phase == 0 ? total : (a.phase == 1 ? tl.n_first : total - tl.n_first);
     }
 
     // The kernels need more dynamic LDS than the default limit: raise it once per kernel and device
@@ -1533,7 +1614,8 @@ namespace asmamd
     static std::atomic<unsigned long long> done{0};
     if (!set_lds_limit(laplace_cart_tiled_kernel<MODE>, done, a.device))
       return false;
-    hipLaunchKernelGGL((laplace_cart_tiled_kernel<MODE>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(NT), LDS_TOTAL * sizeof(double),
+    if (blocks_of_phase(tl, a) > 0)
+      hipLaunchKernelGGL((laplace_cart_tiled_kernel<MODE>), dim3(blocks_of_phase(tl, a)), dim3(NT), LDS_TOTAL * sizeof(double),
                        st, g, op, a, tl);
     return true;
   }
@@ -1547,8 +1629,9 @@ namespace asmamd
     const size_t                           bytes = T2::TOTAL * sizeof(double);
     if (!set_lds_limit(laplace_cart_tiled_kernel2<MODE, TYW>, done, a.device, bytes))
       return false;
-    const Tiling tl = make_tiling(g, a.n_cu, T2::OYW);
-    hipLaunchKernelGGL((laplace_cart_tiled_kernel2<MODE, TYW>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(T2::NTW), bytes, st, g, op, a, tl);
+    const Tiling tl = make_tiling(g, a, T2::OYW);
+    if (blocks_of_phase(tl, a) > 0)
+      hipLaunchKernelGGL((laplace_cart_tiled_kernel2<MODE, TYW>), dim3(blocks_of_phase(tl, a)), dim3(T2::NTW), bytes, st, g, op, a, tl);
     return true;
   }
 
@@ -1574,7 +1657,7 @@ namespace asmamd
           }
 #undef ASM_LAUNCH2
       }
-    const Tiling tl = make_tiling(g, a.n_cu);
+    const Tiling tl = make_tiling(g, a);
     if (a.mode == OP_PLAIN)
       return launch_laplace_tiled<OP_PLAIN>(g, op, a, tl, st);
     if (a.mode == OP_RESIDUAL)
@@ -1589,7 +1672,8 @@ namespace asmamd
     static std::atomic<unsigned long long> done{0};
     if (!set_lds_limit(fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>, done, a.device))
       return false;
-    hipLaunchKernelGGL((fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(NT),
+    if (blocks_of_phase(tl, a) > 0)
+      hipLaunchKernelGGL((fdm_tiled_kernel<MODE, HAS_PRE, HAS_POST, TENSOR>), dim3(blocks_of_phase(tl, a)), dim3(NT),
                        LDS_TOTAL * sizeof(double), st, g, f, a, tl);
     return true;
   }
@@ -1623,7 +1707,7 @@ namespace asmamd
   {
     if (g.p != P || f.m != N1 || f.vertex)
       return false;
-    const Tiling tl = make_tiling(g, a.n_cu);
+    const Tiling tl = make_tiling(g, a);
     if (f.has_pre && f.has_post)
       return dispatch_fdm_mode<true, true>(g, f, a, tl, st);
     if (f.has_pre)

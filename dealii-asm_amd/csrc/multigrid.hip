@@ -39,8 +39,10 @@ namespace
   // 1-D tables of one direction (device pointers)
   struct Transfer1D
   {
-    // prolongation: fine logical index I -> first coarse logical index and n1c weights
+    // prolongation: fine logical index I -> first coarse logical index, count and weights (zeros at both ends of
+    // the row trimmed: a fine node that coincides with a coarse node has one entry)
     const int *   p_start;
+    const int *   p_count;
     const double *p_val; // [n_fine][MAX_N1C]
     // restriction: coarse logical index J -> first fine logical index, count and weights
     const int *   r_start;
@@ -66,6 +68,41 @@ namespace
     return (I - b.begin[0]) * b.stride[0] + (J - b.begin[1]) * b.stride[1] + (K - b.begin[2]) * b.stride[2];
   }
 
+  // One direction of a transfer (the Kronecker factors applied one after the other through two intermediate
+  // boxes, each pass at streaming rate): out[I, J, K] (+)= sum_a val[idx][a] in[.. start[idx] + a ..], idx the
+  // output coordinate along dir.
+  struct PassArgs
+  {
+    const int *   start;
+    const int *   count;
+    const double *val;
+    int           val_stride, dir;
+    BoxLayout     in, out; // out.size = loop bounds
+  };
+
+  template <bool ADD>
+  __global__ void __launch_bounds__(256)
+  transfer_pass_kernel(const PassArgs a, double *__restrict__ out, const double *__restrict__ in)
+  {
+    const long long n = (long long)a.out.size[0] * a.out.size[1] * a.out.size[2];
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
+      {
+        int       c[3]  = {(int)(e % a.out.size[0]), (int)((e / a.out.size[0]) % a.out.size[1]),
+                    (int)(e / ((long long)a.out.size[0] * a.out.size[1]))};
+        const long long o  = box_offset(a.out, c[0], c[1], c[2]);
+        const int       id = c[a.dir];
+        const int       cnt = a.count[id];
+        const double *  w   = a.val + (long long)id * a.val_stride;
+        c[a.dir]            = a.start[id];
+        const double *  row = in + box_offset(a.in, c[0], c[1], c[2]);
+        const long long st  = a.in.stride[a.dir];
+        double          sum = 0.;
+        for (int k = 0; k < cnt; ++k)
+          sum = fma(w[k], row[k * st], sum);
+        out[o] = ADD ? out[o] + sum : sum;
+      }
+  }
+
   // dst_fine += P src_coarse: one thread per fine DoF
   __global__ void __launch_bounds__(256)
   prolongate_add_kernel(const TransferArgs t, double *__restrict__ dst, const double *__restrict__ src)
@@ -76,17 +113,18 @@ namespace
         const int I = (int)(e % t.fine.size[0]), J = (int)((e / t.fine.size[0]) % t.fine.size[1]),
                   K = (int)(e / ((long long)t.fine.size[0] * t.fine.size[1]));
         const int     cx = t.d[0].p_start[I], cy = t.d[1].p_start[J], cz = t.d[2].p_start[K];
+        const int     nx = t.d[0].p_count[I], ny = t.d[1].p_count[J], nz = t.d[2].p_count[K];
         const double *wx = t.d[0].p_val + (long long)I * MAX_N1C, *wy = t.d[1].p_val + (long long)J * MAX_N1C,
                      *wz = t.d[2].p_val + (long long)K * MAX_N1C;
         double sum = 0.;
-        for (int c = 0; c < t.d[2].n1c; ++c)
+        for (int c = 0; c < nz; ++c)
           {
             double sy = 0.;
-            for (int b = 0; b < t.d[1].n1c; ++b)
+            for (int b = 0; b < ny; ++b)
               {
                 const double *row = src + box_offset(t.coarse, cx, cy + b, cz + c);
                 double        sx  = 0.;
-                for (int a = 0; a < t.d[0].n1c; ++a)
+                for (int a = 0; a < nx; ++a)
                   sx = fma(wx[a], row[a * t.coarse.stride[0]], sx);
                 sy = fma(wy[b], sx, sy);
               }
@@ -127,6 +165,30 @@ namespace
       }
   }
 
+  // x = Ainv b on the owned box (the dense inverse of the coarsest level's operator): one workgroup per row
+  __global__ void __launch_bounds__(256)
+  dense_apply_kernel(const double *__restrict__ Ainv, const int n, const BoxLayout box, double *__restrict__ x, const double *__restrict__ b)
+  {
+    __shared__ double part[4];
+    const int         r   = blockIdx.x;
+    double            sum = 0.;
+    for (int c = threadIdx.x; c < n; c += 256)
+      {
+        const int I = c % box.size[0], J = (c / box.size[0]) % box.size[1], K = c / (box.size[0] * box.size[1]);
+        sum         = fma(Ainv[(long long)r * n + c], b[box_offset(box, I, J, K)], sum);
+      }
+    for (int o = 32; o > 0; o >>= 1)
+      sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0)
+      part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      {
+        const int I = r % box.size[0], J = (r / box.size[0]) % box.size[1], K = r / (box.size[0] * box.size[1]);
+        x[box_offset(box, I, J, K)] = (part[0] + part[1]) + (part[2] + part[3]);
+      }
+  }
+
   struct Level
   {
     asm_params params;
@@ -135,9 +197,15 @@ namespace
     double *   x = nullptr, *b = nullptr, *r = nullptr; // solution, defect, work vector
     // transfer to the next coarser level (levels >= 1)
     TransferArgs        transfer;
+    // intermediate boxes of the direction-by-direction transfer: [fine x][fine y][coarse z], [fine x][coarse y][coarse z]
+    double *            pass_xy = nullptr, *pass_x = nullptr;
     std::vector<void *> allocs;
   };
 } // namespace
+
+// context.hip: pool of solver work vectors of a context (not part of the public interface)
+extern "C" int  asm_work_vector_acquire(asm_ctx *ctx, double **v);
+extern "C" void asm_work_vector_release(asm_ctx *ctx, double *v);
 
 struct asm_mg
 {
@@ -147,6 +215,9 @@ struct asm_mg
   int                device = 0;
   // coarse CG work vectors (level 0)
   double *    cg_p = nullptr, *cg_z = nullptr, *cg_q = nullptr;
+  // ASM_MG_COARSE_DIRECT: dense inverse of the level-0 operator, [n][n] over the owned DoFs
+  double *    coarse_inverse = nullptr;
+  int         coarse_n       = 0;
   std::string error;
 };
 
@@ -315,9 +386,23 @@ namespace
         if (constrained(pf, nf, I) || constrained(pc, nc, J))
           P[(size_t)I * nc + J] = 0.;
     std::vector<double> p_val((size_t)nf * MAX_N1C, 0.);
+    std::vector<int>    p_count(nf, 0);
     for (int I = 0; I < nf; ++I)
-      for (int j = 0; j < n1c; ++j)
-        p_val[(size_t)I * MAX_N1C + j] = P[(size_t)I * nc + p_start[I] + j];
+      {
+        int lo = n1c, hi = -1;
+        for (int j = 0; j < n1c; ++j)
+          if (P[(size_t)I * nc + p_start[I] + j] != 0.)
+            {
+              lo = std::min(lo, j);
+              hi = std::max(hi, j);
+            }
+        if (hi < lo)
+          continue; // constrained row
+        p_start[I] += lo;
+        p_count[I] = hi - lo + 1;
+        for (int j = 0; j < p_count[I]; ++j)
+          p_val[(size_t)I * MAX_N1C + j] = P[(size_t)I * nc + p_start[I] + j];
+      }
     std::vector<int>    r_start(nc, 0), r_count(nc, 0);
     std::vector<double> r_val((size_t)nc * MAX_SUP, 0.);
     for (int J = 0; J < nc; ++J)
@@ -344,7 +429,7 @@ namespace
     out.n_fine   = nf;
     out.n_coarse = nc;
     out.n1c      = n1c;
-    if (!upload(lv, p_start, &out.p_start) || !upload(lv, p_val, &out.p_val) || !upload(lv, r_start, &out.r_start) ||
+    if (!upload(lv, p_start, &out.p_start) || !upload(lv, p_count, &out.p_count) || !upload(lv, p_val, &out.p_val) || !upload(lv, r_start, &out.r_start) ||
         !upload(lv, r_count, &out.r_count) || !upload(lv, r_val, &out.r_val))
       {
         error = "transfer: device allocation failed";
@@ -370,6 +455,40 @@ namespace
   launch_blocks(const long long n)
   {
     return (int)std::min<long long>(std::max<long long>((n + 255) / 256, 1), 1 << 16);
+  }
+
+  BoxLayout
+  dense_box(const int nx, const int ny, const int nz)
+  {
+    BoxLayout b;
+    b.begin[0] = b.begin[1] = b.begin[2] = 0;
+    b.size[0]                            = nx;
+    b.size[1]                            = ny;
+    b.size[2]                            = nz;
+    b.stride[0]                          = 1;
+    b.stride[1]                          = nx;
+    b.stride[2]                          = (long long)nx * ny;
+    return b;
+  }
+
+  PassArgs
+  prolongation_pass(const TransferArgs &t, const int dir, const BoxLayout &in, const BoxLayout &out)
+  {
+    return PassArgs{t.d[dir].p_start, t.d[dir].p_count, t.d[dir].p_val, MAX_N1C, dir, in, out};
+  }
+
+  PassArgs
+  restriction_pass(const TransferArgs &t, const int dir, const BoxLayout &in, const BoxLayout &out)
+  {
+    return PassArgs{t.d[dir].r_start, t.d[dir].r_count, t.d[dir].r_val, MAX_SUP, dir, in, out};
+  }
+
+  template <bool ADD>
+  void
+  launch_pass(asm_mg *mg, const PassArgs &a, double *out, const double *in)
+  {
+    const long long n = (long long)a.out.size[0] * a.out.size[1] * a.out.size[2];
+    hipLaunchKernelGGL((transfer_pass_kernel<ADD>), dim3(launch_blocks(n)), dim3(256), 0, mg->stream, a, out, in);
   }
 
   int
@@ -443,12 +562,12 @@ namespace
     ~WorkVectors()
     {
       for (double *p : v)
-        (void)asm_vector_free(ctx, p);
+        asm_work_vector_release(ctx, p);
     }
     double *get()
     {
       double *p = nullptr;
-      if (asm_vector_alloc(ctx, &p) != ASM_OK)
+      if (asm_work_vector_acquire(ctx, &p) != ASM_OK)
         return nullptr;
       v.push_back(p);
       return p;
@@ -630,6 +749,88 @@ namespace
   }
 
   // ---- V-cycle (deal.II Multigrid::level_v_step) -----------------------------------------------------
+  // Dense inverse of the level-0 operator: its columns from the level context's own sweep, constrained rows and
+  // columns replaced by the identity, inverted by Cholesky factorisation on the host (the level has a few hundred DoFs).
+  constexpr int MAX_COARSE_DIRECT = 2048;
+
+  int
+  build_coarse_inverse(asm_mg *mg, std::string &error)
+  {
+    Level &        lv  = mg->levels[0];
+    asm_ctx *const ctx = lv.ctx;
+    const int      n   = (int)((long long)lv.layout.owned_size[0] * lv.layout.owned_size[1] * lv.layout.owned_size[2]);
+    if ((long long)lv.layout.owned_size[0] * lv.layout.owned_size[1] * lv.layout.owned_size[2] > MAX_COARSE_DIRECT)
+      {
+        error = "direct coarse-grid solver: the coarsest level has more than " + std::to_string(MAX_COARSE_DIRECT) +
+                " DoFs (the numbers of cells must be divisible by a power of two for h-coarsening to get there)";
+        return ASM_ERR_NOT_SUPPORTED;
+      }
+    std::vector<double> A((size_t)n * n), e(n, 0.);
+    for (int j = 0; j < n; ++j)
+      {
+        e[j] = 1.;
+        KS_CTX(asm_vector_import(lv.ctx, lv.b, e.data()));
+        KS_CTX(asm_op_vmult(lv.ctx, lv.x, lv.b));
+        KS_CTX(asm_vector_export(lv.ctx, &A[(size_t)j * n], lv.x));
+        e[j] = 0.;
+      }
+    for (int j = 0; j < n; ++j)
+      if (A[(size_t)j * n + j] == 0.) // constrained DoF
+        A[(size_t)j * n + j] = 1.;
+    // A = L L^T (lower triangle, in place)
+    for (int j = 0; j < n; ++j)
+      {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k)
+          d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0.))
+          {
+            error = "direct coarse-grid solver: the level operator is not positive definite (pure Neumann problem?)";
+            return ASM_ERR_NOT_SUPPORTED;
+          }
+        const double ljj     = std::sqrt(d);
+        A[(size_t)j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i)
+          {
+            double v = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k)
+              v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = v / ljj;
+          }
+      }
+    // columns of the inverse: L y = e_j, L^T x = y (x is row j of the symmetric inverse)
+    std::vector<double> inv((size_t)n * n), y(n), U((size_t)n * n); // U = L^T, rows contiguous
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k <= i; ++k)
+        U[(size_t)k * n + i] = A[(size_t)i * n + k];
+    for (int j = 0; j < n; ++j)
+      {
+        for (int i = 0; i < n; ++i)
+          {
+            double v = i == j ? 1. : 0.;
+            if (i >= j)
+              for (int k = j; k < i; ++k)
+                v -= A[(size_t)i * n + k] * y[k];
+            y[i] = i >= j ? v / A[(size_t)i * n + i] : 0.;
+          }
+        for (int i = n - 1; i >= 0; --i)
+          {
+            double v = y[i];
+            for (int k = i + 1; k < n; ++k)
+              v -= U[(size_t)i * n + k] * inv[(size_t)j * n + k];
+            inv[(size_t)j * n + i] = v / A[(size_t)i * n + i];
+          }
+      }
+    if (hipMalloc((void **)&mg->coarse_inverse, inv.size() * sizeof(double)) != hipSuccess ||
+        hipMemcpy(mg->coarse_inverse, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      {
+        error = "direct coarse-grid solver: device allocation failed";
+        return ASM_ERR_DEVICE;
+      }
+    mg->coarse_n = n;
+    return ASM_OK;
+  }
+
   int
   v_cycle(asm_mg *mg, const int level)
   {
@@ -640,6 +841,12 @@ namespace
           {
             MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, lv.x, lv.b));
             return ASM_OK;
+          }
+        if (mg->mp.coarse_solver == ASM_MG_COARSE_DIRECT)
+          {
+            hipLaunchKernelGGL(dense_apply_kernel, dim3(mg->coarse_n), dim3(256), 0, mg->stream, mg->coarse_inverse, mg->coarse_n,
+                               box_of(lv.layout), lv.x, lv.b);
+            return check_launch(mg, "coarse solve");
           }
         // MGCoarseGridIterativeSolver-like: Jacobi-preconditioned CG (the level-0 context is a diagonal one)
         asm_solver_params sp;
@@ -707,6 +914,8 @@ asm_mg_destroy(asm_mg *mg)
     for (double *v : {mg->cg_p, mg->cg_z, mg->cg_q})
       if (v)
         (void)asm_vector_free(mg->levels[0].ctx, v);
+  if (mg->coarse_inverse)
+    (void)hipFree(mg->coarse_inverse);
   for (Level &lv : mg->levels)
     {
       if (lv.ctx)
@@ -736,6 +945,11 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
       g_mg_create_error = "multigrid level hierarchies are built on one rank only (world_size must be 1)";
       return ASM_ERR_NOT_SUPPORTED;
     }
+  if (mp.coarse_solver < ASM_MG_COARSE_SMOOTHER || mp.coarse_solver > ASM_MG_COARSE_DIRECT)
+    {
+      g_mg_create_error = "unknown coarse-grid solver";
+      return ASM_ERR_INVALID_VALUE;
+    }
   if (mp.mg_type < ASM_MG_H || mp.mg_type > ASM_MG_PH || mp.p_sequence < ASM_MG_BISECT || mp.p_sequence > ASM_MG_GO_TO_ONE)
     {
       g_mg_create_error = "Multigrid variant / p sequence is not known!";
@@ -761,7 +975,7 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
       lv.params.degree = specs[l].p;
       lv.params.rank   = 0;
       // the coarse CG solve is Jacobi-preconditioned; vertex-star patches need degree >= 2
-      if ((l == 0 && mp.coarse_solver == ASM_MG_COARSE_CG) || (lv.params.element_centric == 0 && specs[l].p < 2))
+      if ((l == 0 && mp.coarse_solver != ASM_MG_COARSE_SMOOTHER) || (lv.params.element_centric == 0 && specs[l].p < 2))
         {
           lv.params.precond_type    = ASM_PRECOND_DIAGONAL;
           lv.params.element_centric = 1; // (no patches are built for the diagonal smoother)
@@ -796,6 +1010,24 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
         }
       lv.transfer.fine   = box_of(lv.layout);
       lv.transfer.coarse = box_of(mg->levels[l - 1].layout);
+      // larger levels: one pass per direction (ASM_MG_DIRECT_TRANSFER keeps the single-kernel form everywhere)
+      const TransferArgs &t = lv.transfer;
+      if ((long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2] >= (1 << 17) && std::getenv("ASM_MG_DIRECT_TRANSFER") == nullptr)
+        {
+          const size_t n_xy = (size_t)t.fine.size[0] * t.fine.size[1] * t.coarse.size[2], n_x = (size_t)t.fine.size[0] * t.coarse.size[1] * t.coarse.size[2];
+          void *       q = nullptr;
+          if (hipMalloc(&q, (n_xy + n_x) * sizeof(double)) != hipSuccess)
+            return fail(ASM_ERR_DEVICE, "transfer work space allocation failed");
+          lv.allocs.push_back(q);
+          lv.pass_xy = (double *)q;
+          lv.pass_x  = lv.pass_xy + n_xy;
+        }
+    }
+  if (mp.coarse_solver == ASM_MG_COARSE_DIRECT)
+    {
+      std::string error;
+      if (const int err = build_coarse_inverse(mg, error))
+        return fail(err, error);
     }
   if (mp.estimate_eigenvalues)
     for (size_t l = 0; l < specs.size(); ++l)
@@ -840,6 +1072,17 @@ asm_mg_prolongate_add(asm_mg *mg, int32_t level, double *dst_fine, const double 
   const DeviceGuard   guard(mg->device);
   const TransferArgs &t = mg->levels[level].transfer;
   const long long     n = (long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2];
+  if (mg->levels[level].pass_xy)
+    {
+      // x, y, z: coarse -> [fine x][coarse y][coarse z] -> [fine x][fine y][coarse z] -> fine (+=)
+      const Level &   lv = mg->levels[level];
+      const BoxLayout bx = dense_box(t.fine.size[0], t.coarse.size[1], t.coarse.size[2]),
+                      bxy = dense_box(t.fine.size[0], t.fine.size[1], t.coarse.size[2]);
+      launch_pass<false>(mg, prolongation_pass(t, 0, t.coarse, bx), lv.pass_x, src_coarse);
+      launch_pass<false>(mg, prolongation_pass(t, 1, bx, bxy), lv.pass_xy, lv.pass_x);
+      launch_pass<true>(mg, prolongation_pass(t, 2, bxy, t.fine), dst_fine, lv.pass_xy);
+      return check_launch(mg, "prolongate_add");
+    }
   hipLaunchKernelGGL(prolongate_add_kernel, dim3(launch_blocks(n)), dim3(256), 0, mg->stream, t, dst_fine, src_coarse);
   return check_launch(mg, "prolongate_add");
 }
@@ -855,6 +1098,17 @@ asm_mg_restrict(asm_mg *mg, int32_t level, double *dst_coarse, const double *src
   const DeviceGuard   guard(mg->device);
   const TransferArgs &t = mg->levels[level].transfer;
   const long long     n = (long long)t.coarse.size[0] * t.coarse.size[1] * t.coarse.size[2];
+  if (mg->levels[level].pass_xy)
+    {
+      // z, y, x: fine -> [fine x][fine y][coarse z] -> [fine x][coarse y][coarse z] -> coarse
+      const Level &   lv = mg->levels[level];
+      const BoxLayout bx = dense_box(t.fine.size[0], t.coarse.size[1], t.coarse.size[2]),
+                      bxy = dense_box(t.fine.size[0], t.fine.size[1], t.coarse.size[2]);
+      launch_pass<false>(mg, restriction_pass(t, 2, t.fine, bxy), lv.pass_xy, src_fine);
+      launch_pass<false>(mg, restriction_pass(t, 1, bxy, bx), lv.pass_x, lv.pass_xy);
+      launch_pass<false>(mg, restriction_pass(t, 0, bx, t.coarse), dst_coarse, lv.pass_x);
+      return check_launch(mg, "restrict");
+    }
   hipLaunchKernelGGL(restrict_kernel, dim3(launch_blocks(n)), dim3(256), 0, mg->stream, t, dst_coarse, src_fine);
   return check_launch(mg, "restrict");
 }

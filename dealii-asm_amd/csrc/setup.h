@@ -17,6 +17,7 @@
 #include "numerics.h"
 
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -97,6 +98,10 @@ namespace asmamd
     int        P[3], pc[3], cell_begin[3], ncg[3];
     int        face[3][2]; // FaceKind of the local block's faces
     int        nbr[3][2];  // neighbour rank per face or -1
+    // Hardware test mode (ASM_SELF_INTERFACE, one rank): a periodic direction is closed through ghost planes and
+    // messages of the rank to itself instead of index wrap-around, so that the whole multi-rank path (plans, RCCL
+    // send/recv, overlap streams, compress(add), all-reduce) runs on a single GPU.
+    bool       self_interface = false;
     DevGrid    g;
     int        store_size[3];
     long long  n_alloc, n_owned, n_ghost, n_global;
@@ -264,6 +269,8 @@ namespace asmamd
     s.fdm_tiled     = s.kernel == ASM_KERNEL_TILED && fdm_ok;
     s.laplace_tiled = s.kernel == ASM_KERNEL_TILED && laplace_ok;
 
+    s.self_interface = prm.world_size == 1 && std::getenv("ASM_SELF_INTERFACE") != nullptr &&
+                       (prm.boundary[0][0] == ASM_BC_PERIODIC || prm.boundary[1][0] == ASM_BC_PERIODIC || prm.boundary[2][0] == ASM_BC_PERIODIC);
     DevGrid &g = s.g;
     g.p        = p;
     g.n1       = p + 1;
@@ -288,8 +295,9 @@ namespace asmamd
               }
             else if (periodic)
               {
-                s.face[d][f] = (P[d] == 1) ? FACE_WRAP : FACE_INTERFACE;
-                s.nbr[d][f]  = (P[d] == 1) ? -1 : nbr_rank;
+                const bool wrap = P[d] == 1 && !s.self_interface;
+                s.face[d][f]    = wrap ? FACE_WRAP : FACE_INTERFACE;
+                s.nbr[d][f]     = wrap ? -1 : nbr_rank;
               }
             else
               {

@@ -364,7 +364,9 @@ enum asm_mg_p_sequence
 enum asm_mg_coarse
 {
   ASM_MG_COARSE_SMOOTHER = 0, /* the level-0 Chebyshev smoother's vmult (tests/.../small fixtures) */
-  ASM_MG_COARSE_CG       = 1  /* Jacobi-preconditioned CG to a relative tolerance (in place of AMG) */
+  ASM_MG_COARSE_CG       = 1, /* Jacobi-preconditioned CG to a relative tolerance (in place of AMG) */
+  ASM_MG_COARSE_DIRECT   = 2  /* dense inverse of the level operator, built at creation (levels of <= 2048 DoFs): one
+                               * kernel per coarse solve and a linear V-cycle, also in place of AMG */
 };
 
 typedef struct asm_mg_params

@@ -155,6 +155,24 @@ class CoarseCG:
         return x
 
 
+class CoarseDirect:
+    """Coarse solve with the dense level matrix (identity on constrained rows and columns): the twin of
+    ASM_MG_COARSE_DIRECT, also in place of the reference's AMG V-cycle."""
+
+    def __init__(self, op):
+        n = op.mesh.n_dofs
+        A = np.zeros((n, n))
+        e = np.zeros(n)
+        for j in range(n):
+            e[j] = 1.0
+            A[:, j] = op.vmult(e, unit_constrained=True)
+            e[j] = 0.0
+        self.A = A
+
+    def vmult(self, b, unit_constrained=True):
+        return np.linalg.solve(self.A, b)
+
+
 # --------------------------------------------------------------------------
 # outer solvers (SolverControl semantics of ReductionControl: stop when the residual norm is
 # <= max(abs_tol, rel_tol * initial residual); the count returned is SolverControl::last_step())

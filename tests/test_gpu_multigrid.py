@@ -28,6 +28,8 @@ def oracle_hierarchy(nc, p, bc, mg_type, weighting, n_overlap, degree, lams, geo
     def coarse_factory(mesh, op):
         if coarse == "smoother":
             return smoother(0, mesh, op)
+        if coarse == "direct":
+            return omg.CoarseDirect(op)
         return omg.CoarseCG(op, rel_tol=coarse_rel_tol)
 
     return omg.build_multigrid(nc, p, bcs, smoother, coarse_factory, mg_type=mg_type, p_sequence=p_sequence, mapfn=mapfn,
@@ -43,6 +45,10 @@ def oracle_hierarchy(nc, p, bc, mg_type, weighting, n_overlap, degree, lams, geo
         ((8, 4, 4), 1, "dirichlet", "h", "bisect"),
         ((4, 4, 2), 3, ["neumann", "dirichlet", "dirichlet"], "h", "bisect"),
         ((4, 4, 4), 4, "dirichlet", "ph", "bisect"),
+        # levels of >= 2^17 DoFs take the direction-by-direction form of the transfer
+        ((16, 16, 12), 4, ["dirichlet", "neumann", "dirichlet"], "p", "bisect"),
+        ((64, 32, 64), 1, ["neumann", "dirichlet", "dirichlet"], "h", "bisect"),
+        ((12, 12, 12), 7, "dirichlet", "p", "decrease by one"),
     ],
 )
 def test_transfer_parity(pkg, nc, p, bc, mg_type, p_sequence):
@@ -67,6 +73,28 @@ def test_transfer_parity(pkg, nc, p, bc, mg_type, p_sequence):
             assert rel(wc.get(), T.restrict(rf)) < TOL
             for v in (vc, vf, wf, wc):
                 v.free()
+
+
+def test_transfer_forms_agree(pkg, monkeypatch):
+    """the single-kernel and the direction-by-direction form of the transfers give the same result (rounding apart)"""
+    prm = fine_params(pkg, (20, 16, 12), 4, ["dirichlet", "neumann", "dirichlet"])
+    rng = np.random.default_rng(11)
+    out = []
+    for direct in (False, True):
+        if direct:
+            monkeypatch.setenv("ASM_MG_DIRECT_TRANSFER", "1")
+        with pkg.Multigrid(prm, mg_type="ph", estimate_eigenvalues=False) as mg:
+            l = mg.n_levels - 1
+            cf, cc = mg.levels[l], mg.levels[l - 1]
+            if not out:
+                xc, xf = rng.uniform(-1, 1, cc.n_dofs), rng.uniform(-1, 1, cf.n_dofs)
+            vc, vf, wc = cc.vector(xc), cf.vector(xf), cc.vector()
+            mg.restrict(l, wc, vf)
+            mg.prolongate_add(l, vf, vc)
+            out.append((vf.get(), wc.get()))
+            for v in (vc, vf, wc):
+                v.free()
+    assert rel(out[0][0], out[1][0]) < TOL and rel(out[0][1], out[1][1]) < TOL
 
 
 @pytest.mark.parametrize(
@@ -181,3 +209,40 @@ def test_multigrid_refuses_what_it_does_not_cover(pkg):
         pkg.Multigrid(fine_params(pkg, (4, 4, 4), 4, "periodic"), mg_type="p")
     with pytest.raises(RuntimeError, match="one rank"):
         pkg.Multigrid(pkg.make_params(degree=2, n_cells=(4, 4, 4), world_size=2, rank=0))
+
+
+@pytest.mark.parametrize(
+    "nc,p,bc,geometry,mg_type,solver,weighting,degree",
+    [
+        ((8, 8, 4), 4, "dirichlet", "cartesian", "ph", "GMRES", "post", 1),
+        ((4, 4, 4), 3, ["dirichlet", "neumann", "dirichlet"], "cartesian", "h", "CG", "symm", 2),
+        ((6, 4, 2), 4, "dirichlet", "kershaw", "p", "GMRES", "post", 2),
+    ],
+)
+def test_direct_coarse_solver(pkg, nc, p, bc, geometry, mg_type, solver, weighting, degree):
+    """coarse-grid solver = dense inverse of the level operator: the V-cycle is linear and agrees with the oracle twin to
+    rounding, and so do the iteration counts and the solution of a preconditioned solve"""
+    prm = fine_params(pkg, nc, p, bc, geometry, weighting=weighting, cheb_degree=degree)
+    with pkg.Multigrid(prm, mg_type=mg_type, coarse="direct") as mg:
+        M, meshes, ops = oracle_hierarchy(nc, p, bc, mg_type, weighting, 1, degree, None, geometry, coarse="direct")
+        mesh, op = meshes[-1], ops[-1]
+        b = np.random.default_rng(3).uniform(0, 1, mesh.n_dofs)
+        b[mesh.constrained_mask()] = 0.0
+        bv, xv = mg.fine.vector(b), mg.fine.vector()
+        mg.vmult(xv, bv)
+        assert rel(xv.get(), M.vmult(b)) < 1e-9  # eigenvalue estimates of both sides agree to ~1e-10 only
+        fn = omg.solve_gmres if solver == "GMRES" else omg.solve_cg
+        x_ref, it_ref = fn(op, b, M, rel_tol=1e-8, abs_tol=0.0)
+        res = mg.fine.solve(xv, bv, solver=solver, preconditioner="Multigrid", mg=mg, rel_tol=1e-8, abs_tol=0.0)
+        assert res.converged == 1 and res.n_iterations == it_ref, (res.n_iterations, it_ref)
+        assert rel(xv.get(), x_ref) < 1e-7
+        true_res = np.linalg.norm(b - op.vmult(xv.get(), unit_constrained=True))
+        assert true_res <= 1.01e-8 * np.linalg.norm(b)  # linear preconditioner: the GMRES estimate is the true residual
+        bv.free()
+        xv.free()
+
+
+def test_direct_coarse_solver_refuses_large_levels(pkg):
+    prm = fine_params(pkg, (13, 13, 13), 1, "dirichlet")
+    with pytest.raises(Exception, match="direct coarse-grid solver"):
+        pkg.Multigrid(prm, mg_type="h", coarse="direct")

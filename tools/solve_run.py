@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--rel-tol", type=float, default=1e-5)
     ap.add_argument("--tmp-vectors", type=int, default=17)
     ap.add_argument("--best-of", type=int, default=5)
-    ap.add_argument("--coarse", default="cg", choices=["cg", "smoother"])
+    ap.add_argument("--coarse", default="cg", choices=["cg", "smoother", "direct"])
     args = ap.parse_args()
     pkg = load_package()
     prm = pkg.make_params(degree=4, n_cells=args.cells, boundary="dirichlet", geometry=args.geometry, kershaw_eps=(0.3, 0.3),
