@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs):
   kershaw         Kershaw eps=0.3 (experiments/large-scaling-opt_fdm1.json), Q2 geometry
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -118,6 +119,21 @@ def cpu_baseline(args, pkg, cells):
     }
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on stdout (file descriptor 1) when a communicator is created; stdout carries the
+    one JSON line of this script and nothing else"""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +209,8 @@ def main():
 
         uid = [pkg.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0])
+        with stdout_to_stderr():
+            ctx.comm_init(uid[0])
         # the timed loop modifies its vectors through the library only: the exchange of a step's result
         # (overlapped with the sweep that produces it) then serves the next step, as asm_set_keep_ghosts documents
         ctx.set_keep_ghosts(True)
@@ -201,7 +218,8 @@ def main():
     if self_interface:
         # rehearsal of the multi-rank path on one GPU (tests/test_gpu_rccl_self.py): the rank exchanges its 26 ghost
         # messages with itself through RCCL; not a bench configuration, the line says so
-        ctx.comm_init(pkg.comm_unique_id())
+        with stdout_to_stderr():
+            ctx.comm_init(pkg.comm_unique_id())
         ctx.set_keep_ghosts(True)
 
     def barrier():

@@ -1179,13 +1179,22 @@ asm_create(const asm_params *p, asm_ctx **out)
           bool ok = true;
           for (int d = 0; d < 3 && ok; ++d)
             {
-              // longest run of cells with one parity-sorted instance
+              // longest run of cells with one parity-sorted instance and the same rows of weight factors
+              // (the kernel reads both as scalar operands)
+              const auto same = [&](const int c0, const int c1) {
+                if (s.inst[d][c0 + 1] != s.inst[d][c1 + 1])
+                  return false;
+                for (int i = 0; i < 7; ++i)
+                  if (s.w_pre[d][(c0 + 1) * 7 + i] != s.w_pre[d][(c1 + 1) * 7 + i] || s.w_post[d][(c0 + 1) * 7 + i] != s.w_post[d][(c1 + 1) * 7 + i])
+                    return false;
+                return true;
+              };
               int best_lo = 0, best_len = 0;
               for (int c = 0; c < s.g.nc[d];)
                 {
                   const int id = s.inst[d][c + 1];
                   int       e  = c;
-                  while (e < s.g.nc[d] && s.inst[d][e + 1] == id)
+                  while (e < s.g.nc[d] && same(c, e))
                     ++e;
                   if (s.eig_sym[id] != 0 && e - c > best_len)
                     {
@@ -1209,6 +1218,15 @@ asm_create(const asm_params *p, asm_ctx **out)
                     inv[(c * m + b) * m + a] = 1.0 / (s.eig[(size_t)f.s7_inst[0] * E + m * m + a] +
                                                       (s.eig[(size_t)f.s7_inst[1] * E + m * m + b] + s.eig[(size_t)f.s7_inst[2] * E + m * m + c]));
               UP(inv, &f.s7_inv);
+              for (int k = 0; k < 2; ++k)
+                {
+                  const std::vector<double> &wx = k == 0 ? s.w_pre[0] : s.w_post[0], &wy = k == 0 ? s.w_pre[1] : s.w_post[1];
+                  std::vector<double>        wxy(49);
+                  for (int j = 0; j < 7; ++j)
+                    for (int i = 0; i < 7; ++i)
+                      wxy[j * 7 + i] = wx[(f.s7_lo[0] + 1) * 7 + i] * wy[(f.s7_lo[1] + 1) * 7 + j];
+                  UP(wxy, &f.s7_wxy[k]);
+                }
               std::vector<int> others;
               for (int cz = 0; cz < s.g.nc[2]; ++cz)
                 for (int cy = 0; cy < s.g.nc[1]; ++cy)

@@ -578,8 +578,10 @@ namespace asmamd
     }
 
     // DIAG = false: dst += A src (scatter-add);  DIAG = true: dst += diag(A)
-    template <int P, bool DIAG>
-    __global__ void __launch_bounds__(BLOCK)
+    // CART: box cells (op.h) / deformed cells (op.coeff): one instantiation each, so that neither carries the
+    // registers and the code of the other geometry
+    template <int P, bool DIAG, bool CART>
+    __global__ void __launch_bounds__(BLOCK, CART ? (P <= 5 ? 4 : 2) : (P <= 4 ? 3 : 2))
     laplace_generic_kernel(const DevGrid g, const DevOp op, const double *__restrict__ src, double *__restrict__ dst, const double sign)
     {
       using C           = OpCfg<P>;
@@ -611,7 +613,7 @@ namespace asmamd
           c3[0] = cell % g.nc[0];
           c3[1] = (cell / g.nc[0]) % g.nc[1];
           c3[2] = cell / (g.nc[0] * g.nc[1]);
-          if (!op.cartesian)
+          if (!CART)
             {
               const long long ce = (c3[0] + 1) + (g.nc[0] + 2) * ((c3[1] + 1) + (long long)(g.nc[1] + 2) * (c3[2] + 1));
               for (int e = lt; e < 81; e += N2)
@@ -624,7 +626,6 @@ namespace asmamd
       bool      valid[N1];
       long long off[N1];
       double    diag_acc[N1];
-      // ---- gather: thread (j=b, i=a) holds the column along z --------------
       {
         const int  I = P * c3[0] + a, J = P * c3[1] + b;
         const bool vxy = active && g.exists(0, I) && g.exists(1, J) && !g.dirichlet(0, I) && !g.dirichlet(1, J);
@@ -693,7 +694,7 @@ namespace asmamd
                 vz[q] = T0[lc][q * N2 + b * N1 + a];
               double            hxc = 1., hyc = 1., hzc = 1.;
               CollapsedJacobian cj;
-              if (op.cartesian)
+              if (CART)
                 {
                   hxc = op.h[0][c3[0] + 1];
                   hyc = op.h[1][c3[1] + 1];
@@ -714,7 +715,7 @@ namespace asmamd
                     }
                   const double w = wqs[a] * wqs[b] * wqs[qz];
                   double       ox, oy, oz;
-                  if (op.cartesian)
+                  if (CART)
                     {
                       const double det = hxc * hyc * hzc * w;
                       ox               = gx * det / (hxc * hxc);
@@ -875,7 +876,10 @@ namespace asmamd
   {
     const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
     const int blocks = (ncells + OpCfg<P>::CPB - 1) / OpCfg<P>::CPB;
-    hipLaunchKernelGGL((laplace_generic_kernel<P, DIAG>), dim3(blocks), dim3(BLOCK), 0, st, g, op, src, dst, sign);
+    if (op.cartesian)
+      hipLaunchKernelGGL((laplace_generic_kernel<P, DIAG, true>), dim3(blocks), dim3(BLOCK), 0, st, g, op, src, dst, sign);
+    else
+      hipLaunchKernelGGL((laplace_generic_kernel<P, DIAG, false>), dim3(blocks), dim3(BLOCK), 0, st, g, op, src, dst, sign);
   }
 
   bool

@@ -134,7 +134,7 @@ namespace asmamd
     };
 
     template <bool HAS_PRE, bool HAS_POST>
-    __global__ void __launch_bounds__(WPB * 64)
+    __global__ void __launch_bounds__(WPB * 64, 3)
     fdm_slice7_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const double *__restrict__ src, double *__restrict__ tmp)
     {
       __shared__ double S_T[WPB * TB7];
@@ -180,19 +180,13 @@ namespace asmamd
         }
       if (HAS_PRE)
         {
-          const double wz = f.w_pre[2][(cz + 1) * M + sub];
-          double       wx[M];
+          // the rows of weight factors are the same for every cell of the region: their x-y products are scalar
+          // operands, the z factor belongs to the lane's plane
+          const UniformMatrix7 wxy(f.s7_wxy[0]);
+          const double         wz = f.w_pre[2][(sa.lo[2] + 1) * M + sub];
 #pragma unroll
-          for (int i = 0; i < M; ++i)
-            wx[i] = f.w_pre[0][(cx + 1) * M + i];
-#pragma unroll
-          for (int j = 0; j < M; ++j)
-            {
-              const double wyz = f.w_pre[1][(cy + 1) * M + j] * wz;
-#pragma unroll
-              for (int i = 0; i < M; ++i)
-                v[j * M + i] *= wx[i] * wyz;
-            }
+          for (int e = 0; e < M2; ++e)
+            v[e] = (v[e] * wxy[e]) * wz;
         }
       const UniformMatrix7 Qx(sa.qx), Qy(sa.qy), Qz(sa.qz);
       sweep_fast7<true>(v, Qx);  // i -> a
@@ -213,19 +207,13 @@ namespace asmamd
       sweep_fast7<false>(v, Qx);
       if (HAS_POST)
         {
-          const double wz = f.w_post[2][(cz + 1) * M + sub];
-          double       wx[M];
+          // the rows of weight factors are the same for every cell of the region: their x-y products are scalar
+          // operands, the z factor belongs to the lane's plane
+          const UniformMatrix7 wxy(f.s7_wxy[1]);
+          const double         wz = f.w_post[2][(sa.lo[2] + 1) * M + sub];
 #pragma unroll
-          for (int i = 0; i < M; ++i)
-            wx[i] = f.w_post[0][(cx + 1) * M + i];
-#pragma unroll
-          for (int j = 0; j < M; ++j)
-            {
-              const double wyz = f.w_post[1][(cy + 1) * M + j] * wz;
-#pragma unroll
-              for (int i = 0; i < M; ++i)
-                v[j * M + i] *= wx[i] * wyz;
-            }
+          for (int e = 0; e < M2; ++e)
+            v[e] = (v[e] * wxy[e]) * wz;
         }
       if (active)
         {

@@ -832,20 +832,23 @@ namespace
   }
 
   int
-  v_cycle(asm_mg *mg, const int level)
+  v_cycle(asm_mg *mg, const int level, double *x = nullptr, double *b = nullptr)
   {
     Level &lv = mg->levels[level];
+    // (the finest level works on the caller's vectors)
+    x = x ? x : lv.x;
+    b = b ? b : lv.b;
     if (level == 0)
       {
         if (mg->mp.coarse_solver == ASM_MG_COARSE_SMOOTHER)
           {
-            MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, lv.x, lv.b));
+            MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, x, b));
             return ASM_OK;
           }
         if (mg->mp.coarse_solver == ASM_MG_COARSE_DIRECT)
           {
             hipLaunchKernelGGL(dense_apply_kernel, dim3(mg->coarse_n), dim3(256), 0, mg->stream, mg->coarse_inverse, mg->coarse_n,
-                               box_of(lv.layout), lv.x, lv.b);
+                               box_of(lv.layout), x, b);
             return check_launch(mg, "coarse solve");
           }
         // MGCoarseGridIterativeSolver-like: Jacobi-preconditioned CG (the level-0 context is a diagonal one)
@@ -857,16 +860,16 @@ namespace
         sp.max_iterations = mg->mp.coarse_max_iterations;
         asm_solver_result res;
         double *const     work[4] = {lv.r, mg->cg_z, mg->cg_p, mg->cg_q};
-        return solve_cg(lv.ctx, Preconditioner{ASM_SP_INNER, lv.ctx, nullptr}, sp, lv.x, lv.b, res, mg->error, work);
+        return solve_cg(lv.ctx, Preconditioner{ASM_SP_INNER, lv.ctx, nullptr}, sp, x, b, res, mg->error, work);
       }
     Level &lc = mg->levels[level - 1];
-    MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, lv.x, lv.b));                                    // pre-smoothing, x_0 = 0
-    MG_CTX(mg, lv.ctx, asm_op_vmult_fused(lv.ctx, ASM_FUSED_RESIDUAL, lv.r, lv.x, lv.b));      // r = b - A x
+    MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, x, b));                                    // pre-smoothing, x_0 = 0
+    MG_CTX(mg, lv.ctx, asm_op_vmult_fused(lv.ctx, ASM_FUSED_RESIDUAL, lv.r, x, b));      // r = b - A x
     MG_TRY(asm_mg_restrict(mg, level, lc.b, lv.r));
     MG_TRY(v_cycle(mg, level - 1));
-    MG_TRY(asm_mg_prolongate_add(mg, level, lv.x, lc.x));
+    MG_TRY(asm_mg_prolongate_add(mg, level, x, lc.x));
     if (!mg->mp.one_sided_v_cycle)
-      MG_CTX(mg, lv.ctx, asm_cheb_step(lv.ctx, lv.x, lv.b));                                   // post-smoothing
+      MG_CTX(mg, lv.ctx, asm_cheb_step(lv.ctx, x, b));                                   // post-smoothing
     return ASM_OK;
   }
 } // namespace
@@ -1118,10 +1121,12 @@ asm_mg_vmult(asm_mg *mg, double *dst, const double *src)
 {
   const DeviceGuard guard(mg->device);
   Level &           top = mg->levels.back();
-  MG_CTX(mg, top.ctx, asm_vec_copy(top.ctx, top.b, src));
-  MG_TRY(v_cycle(mg, (int)mg->levels.size() - 1));
-  MG_CTX(mg, top.ctx, asm_vec_copy(top.ctx, dst, top.x));
-  return ASM_OK;
+  if (dst == src)
+    {
+      MG_CTX(mg, top.ctx, asm_vec_copy(top.ctx, top.b, src));
+      return v_cycle(mg, (int)mg->levels.size() - 1, dst, top.b);
+    }
+  return v_cycle(mg, (int)mg->levels.size() - 1, dst, const_cast<double *>(src)); // (one rank: src is only read)
 }
 
 int
