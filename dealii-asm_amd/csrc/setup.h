@@ -16,11 +16,13 @@
 #include "grid.h"
 #include "numerics.h"
 
+#include <algorithm>
 #include <array>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace asmamd
@@ -686,6 +688,27 @@ namespace asmamd
         }
   }
 
+  // fn(begin, end) on contiguous slices of [0, n) with the host's threads (ASM_SETUP_THREADS, at most 32)
+  template <typename F>
+  inline void
+  parallel_for(const long long n, const F &fn)
+  {
+    int nt = (int)std::min<long long>(std::max(1u, std::thread::hardware_concurrency()), 32);
+    if (const char *e = std::getenv("ASM_SETUP_THREADS"))
+      nt = std::max(1, std::atoi(e));
+    nt = (int)std::min<long long>(nt, std::max<long long>(n / 64, 1));
+    if (nt <= 1)
+      {
+        fn(0, n);
+        return;
+      }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th)
+      x.join();
+  }
+
   // ---------------------------------------------------------------------
   // full setup
   // ---------------------------------------------------------------------
@@ -730,24 +753,27 @@ namespace asmamd
           if (geo.global_cell(d, c) >= 0)
             s.h[d][c + 1] = prm.extent[d] / s.ncg[d];
       }
-    for (int cz = -1; cz <= g.nc[2]; ++cz)
-      for (int cy = -1; cy <= g.nc[1]; ++cy)
-        for (int cx = -1; cx <= g.nc[0]; ++cx)
-          {
-            const int cg[3] = {geo.global_cell(0, cx), geo.global_cell(1, cy), geo.global_cell(2, cz)};
-            const int ce    = s.ext_cell(cx, cy, cz);
-            if (cg[0] < 0 || cg[1] < 0 || cg[2] < 0)
-              continue;
-            s.cell_exists[ce] = 1;
-            if (!s.cartesian)
-              {
-                double v[27][3];
-                geo.q2_points(cg, v);
-                Geometry::to_monomial(v);
-                std::memcpy(&s.coeff[(long long)ce * 81], v, 81 * sizeof(double));
-                geo.harmonic_extent(v, b, &ext[(long long)ce * 3]);
-              }
-          }
+    // (planes of cells are independent: threaded, the deformed case evaluates the geometry of every cell)
+    parallel_for(g.nc[2] + 2, [&](const long long z0, const long long z1) {
+      for (int cz = (int)z0 - 1; cz < (int)z1 - 1; ++cz)
+        for (int cy = -1; cy <= g.nc[1]; ++cy)
+          for (int cx = -1; cx <= g.nc[0]; ++cx)
+            {
+              const int cg[3] = {geo.global_cell(0, cx), geo.global_cell(1, cy), geo.global_cell(2, cz)};
+              const int ce    = s.ext_cell(cx, cy, cz);
+              if (cg[0] < 0 || cg[1] < 0 || cg[2] < 0)
+                continue;
+              s.cell_exists[ce] = 1;
+              if (!s.cartesian)
+                {
+                  double v[27][3];
+                  geo.q2_points(cg, v);
+                  Geometry::to_monomial(v);
+                  std::memcpy(&s.coeff[(long long)ce * 81], v, 81 * sizeof(double));
+                  geo.harmonic_extent(v, b, &ext[(long long)ce * 3]);
+                }
+            }
+    });
 
     if (prm.precond_type != ASM_PRECOND_FDM)
       {
@@ -817,6 +843,68 @@ namespace asmamd
       {
         for (int d = 0; d < 3; ++d)
           s.inst[d].assign(n_ext, 0);
+        // One instance per cell and direction, nearly all of them different on a deformed mesh: (1) the keys (extents of
+        // the cell and its two neighbours, boundary kinds) of all cells, threaded; (2) numbering of the distinct keys in
+        // cell order; (3) one generalized eigenproblem per distinct key, threaded.
+        std::vector<double> keys((size_t)n_ext * 3 * 5, 0.);
+        parallel_for(g.nc[2] + 2, [&](const long long z0, const long long z1) {
+          for (int cz = (int)z0 - 1; cz < (int)z1 - 1; ++cz)
+            for (int cy = -1; cy <= g.nc[1]; ++cy)
+              for (int cx = -1; cx <= g.nc[0]; ++cx)
+                {
+                  const int ce = s.ext_cell(cx, cy, cz);
+                  if (!s.cell_exists[ce])
+                    continue;
+                  const int c3[3] = {cx, cy, cz};
+                  for (int d = 0; d < 3; ++d)
+                    {
+                      // neighbours' extents: only available inside the extended box;
+                      // cells on the rim of the extended box are halo cells whose
+                      // outer neighbours are never needed by owned DoFs of n_overlap=1
+                      // patches, but their own instance must still be right, so
+                      // evaluate the neighbour geometry directly.
+                      double h3[3] = {0., ext[(long long)ce * 3 + d], 0.};
+                      for (int side = 0; side < 2; ++side)
+                        {
+                          int cn[3] = {c3[0], c3[1], c3[2]};
+                          cn[d] += side ? 1 : -1;
+                          const int cg[3] = {geo.global_cell(0, cn[0]), geo.global_cell(1, cn[1]), geo.global_cell(2, cn[2])};
+                          if (cg[d] < 0)
+                            continue;
+                          double e3[3];
+                          if (cn[d] >= -1 && cn[d] <= g.nc[d])
+                            {
+                              const int cne = s.ext_cell(cn[0], cn[1], cn[2]);
+                              e3[d]         = ext[(long long)cne * 3 + d];
+                            }
+                          else
+                            {
+                              double v[27][3];
+                              geo.q2_points(cg, v);
+                              Geometry::to_monomial(v);
+                              geo.harmonic_extent(v, b, e3);
+                            }
+                          h3[side ? 2 : 0] = e3[d];
+                        }
+                      double *key = &keys[((size_t)ce * 3 + d) * 5];
+                      if (vertex)
+                        {
+                          key[0] = h3[1] != 0. ? h3[1] : 1.0;
+                          key[1] = h3[2] != 0. ? h3[2] : 1.0;
+                        }
+                      else
+                        {
+                          key[0] = h3[0];
+                          key[1] = h3[1];
+                          key[2] = h3[2];
+                          key[3] = face_bc(d, c3[d], 0);
+                          key[4] = face_bc(d, c3[d], 1);
+                        }
+                    }
+                }
+        });
+        std::map<std::array<double, 5>, int> ids;
+        std::vector<std::array<double, 5>>   distinct;
         for (int cz = -1; cz <= g.nc[2]; ++cz)
           for (int cy = -1; cy <= g.nc[1]; ++cy)
             for (int cx = -1; cx <= g.nc[0]; ++cx)
@@ -824,49 +912,40 @@ namespace asmamd
                 const int ce = s.ext_cell(cx, cy, cz);
                 if (!s.cell_exists[ce])
                   continue;
-                const int c3[3] = {cx, cy, cz};
                 for (int d = 0; d < 3; ++d)
                   {
-                    // neighbours' extents: only available inside the extended box;
-                    // cells on the rim of the extended box are halo cells whose
-                    // outer neighbours are never needed by owned DoFs of n_overlap=1
-                    // patches, but their own instance must still be right, so
-                    // evaluate the neighbour geometry directly.
-                    double h3[3] = {0., ext[(long long)ce * 3 + d], 0.};
-                    for (int side = 0; side < 2; ++side)
-                      {
-                        int cn[3] = {c3[0], c3[1], c3[2]};
-                        cn[d] += side ? 1 : -1;
-                        const int cg[3] = {geo.global_cell(0, cn[0]), geo.global_cell(1, cn[1]), geo.global_cell(2, cn[2])};
-                        if (cg[d] < 0)
-                          continue;
-                        double e3[3];
-                        if (cn[d] >= -1 && cn[d] <= g.nc[d])
-                          {
-                            const int cne = s.ext_cell(cn[0], cn[1], cn[2]);
-                            e3[d]         = ext[(long long)cne * 3 + d];
-                          }
-                        else
-                          {
-                            double v[27][3];
-                            geo.q2_points(cg, v);
-                            Geometry::to_monomial(v);
-                            geo.harmonic_extent(v, b, e3);
-                          }
-                        h3[side ? 2 : 0] = e3[d];
-                      }
-                    const int lo = face_bc(d, c3[d], 0), hi = face_bc(d, c3[d], 1);
-                    if (vertex)
-                      {
-                        const double h2[3] = {h3[1] != 0. ? h3[1] : 1.0, h3[2] != 0. ? h3[2] : 1.0, 0.};
-                        s.inst[d][ce]      = get_instance(h2, 0, 0);
-                      }
-                    else
-                      s.inst[d][ce] = get_instance(h3, lo, hi);
+                    std::array<double, 5> key;
+                    std::memcpy(key.data(), &keys[((size_t)ce * 3 + d) * 5], 5 * sizeof(double));
+                    const auto it = ids.emplace(key, (int)distinct.size());
+                    if (it.second)
+                      distinct.push_back(key);
+                    s.inst[d][ce] = it.first->second;
                   }
               }
+        const int E = m * m + m;
+        s.eig.assign(distinct.size() * (size_t)E, 0.);
+        s.eig_sym.assign(distinct.size(), 0);
+        parallel_for((long long)distinct.size(), [&](const long long i0, const long long i1) {
+          std::vector<double> M, K, lam, Q;
+          for (long long id = i0; id < i1; ++id)
+            {
+              const std::array<double, 5> &key = distinct[id];
+              const double                 h3[3] = {key[0], key[1], key[2]};
+              if (vertex)
+                fdm_matrices_vertex(b, h3, M, K);
+              else
+                fdm_matrices_element(b, h3, (int)key[3], (int)key[4], n, M, K);
+              generalized_eigen(m, M, K, lam, Q);
+              s.eig_sym[id] = sort_eigenvectors_by_parity(m, Q, lam) ? 1 : 0;
+              std::copy(Q.begin(), Q.end(), s.eig.begin() + id * E);
+              std::copy(lam.begin(), lam.end(), s.eig.begin() + id * E + m * m);
+            }
+        });
+        s.n_inst = (int)distinct.size();
       }
-    s.n_inst = cache.size();
+    if (s.tensor_inst)
+      s.n_inst = cache.size();
+
 
     // ---- weights: tensor products of 1-D tables ---------------------------
     // valence (include/matrix_free.h:676-712) and RAS ownership (:536-673) are
