@@ -1426,6 +1426,7 @@ namespace asmamd
       double top[N1];
       double carry[N1] = {0., 0., 0., 0., 0.};
       int    par       = 0;
+      STAMP_DECL(0) // (diagnostic builds: shares the first-generation kernel's slots)
       gather4_issue(g, gp, a.src, z_first, Gw, true);
       load_top(g, c, a.src, z_first, top);
       gather_wait();
