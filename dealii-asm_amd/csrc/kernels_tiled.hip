@@ -862,6 +862,37 @@ namespace asmamd
     merge_y_and_store(const DevGrid &g, const LayerPlanes &lp, const CellLane &c, const TiledArgs &a, double *__restrict__ Sy,
                       double (&o)[NE], const int K0, const EpilogueOperands<MODE, NPL> &ops STAMP_PARAM)
     {
+      constexpr bool na = EpilogueOperands<MODE, NPL>::need_a, nb = EpilogueOperands<MODE, NPL>::need_b;
+      // fused update + store of the lane's four owned values per plane
+      const auto store_rows = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+          {
+            const long long off = lp.z[k] + c.rowoff;
+            double          rr[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+              rr[i] = fused_update<MODE>(a, o[k * 5 + i], ops.a[na ? k * P + i : 0], ops.b[nb ? k * P + i : 0]);
+#if defined(ASM_ABLATE) && (ASM_ABLATE & 4)
+            if (rr[0] != 1.2345e300)
+              continue;
+#endif
+            dbl2 lo, hi;
+            lo.x = rr[0];
+            lo.y = rr[1];
+            hi.x = rr[2];
+            hi.y = rr[3];
+            *(dbl2_u *)(a.dst + off)     = lo;
+            *(dbl2_u *)(a.dst + off + 2) = hi;
+          }
+      };
+      // Only the rows sub = 0 receive something in the y merge: every other row is final before the barrier and is
+      // stored there, where the wave would otherwise only wait - the eight waves of the workgroup then do not all enter
+      // the vector-memory path together right after the barrier (profiles/r02_tiled_phase_stamps.txt).
+      // Measured: the Laplace sweeps gain 6-9 %, the FDM sweeps (whose second update operand is requested late and
+      // would have to be waited for before the barrier) lose 2-13 %: split for the Laplace modes only.
+      constexpr bool split = (MODE == OP_PLAIN || MODE == OP_RESIDUAL);
+      const bool     late  = !split || (c.below_ok && c.sub == 0);
 #if !(defined(ASM_ABLATE) && (ASM_ABLATE & 8))
       // ---- y: row 4 -> row 0 of the cell above
       if (c.cell_xy && c.sub == N1 - 1)
@@ -874,6 +905,13 @@ namespace asmamd
               slot[k * 5 + i] = o[k * 5 + i];
         }
       STAMP(10);
+      if (split)
+        {
+          // the update operands (and the next layer's staged rows, requested long ago) have arrived
+          gather_wait();
+          if (c.own_row && !late)
+            store_rows();
+        }
       __syncthreads();
       STAMP(11);
       if (c.below_ok && c.sub == 0)
@@ -894,31 +932,12 @@ namespace asmamd
       // ---- fused update + store
       if (c.own_row)
         {
-          constexpr bool na = EpilogueOperands<MODE, NPL>::need_a, nb = EpilogueOperands<MODE, NPL>::need_b;
-          const bool     yd = (c.yd >> c.sub) & 1u;
+          const bool yd = (c.yd >> c.sub) & 1u;
           // all stores are issued back to back; constrained DoFs (boundary cells only) are put
           // right afterwards: their source values would otherwise make every plane's stores wait
           // for the plane before
-#pragma unroll
-          for (int k = 0; k < NPL; ++k)
-            {
-              const long long off = lp.z[k] + c.rowoff;
-              double          rr[P];
-#pragma unroll
-              for (int i = 0; i < P; ++i)
-                rr[i] = fused_update<MODE>(a, o[k * 5 + i], ops.a[na ? k * P + i : 0], ops.b[nb ? k * P + i : 0]);
-#if defined(ASM_ABLATE) && (ASM_ABLATE & 4)
-              if (rr[0] != 1.2345e300)
-                continue;
-#endif
-              dbl2 lo, hi;
-              lo.x = rr[0];
-              lo.y = rr[1];
-              hi.x = rr[2];
-              hi.y = rr[3];
-              *(dbl2_u *)(a.dst + off)     = lo;
-              *(dbl2_u *)(a.dst + off + 2) = hi;
-            }
+          if (late)
+            store_rows();
           // constrained DoFs: zero (plain product) or the identity row (fused modes:
           // (A x)_c = x_c, matrix_free_internal.h:247-255; unit rows of P^-1)
           const unsigned zdm = (g.dirichlet(2, K0) ? 1u : 0u) | ((NPL == P && g.dirichlet(2, K0 + P)) ? 16u : 0u);
