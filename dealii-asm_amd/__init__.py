@@ -179,6 +179,8 @@ EXPORTED_SYMBOLS = [
     "asm_profile_enable",
     "asm_profile_get",
     "asm_vec_dot",
+    "asm_vec_multi_dot",
+    "asm_vec_multi_axpy_norm",
     "asm_vec_axpby",
     "asm_vec_scale",
     "asm_vec_copy",
@@ -250,6 +252,9 @@ def load_library():
     lib.asm_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.asm_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.asm_vec_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.asm_vec_multi_dot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_double)]
+    lib.asm_vec_multi_axpy_norm.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.c_int32,
+                                            C.POINTER(C.c_double)]
     lib.asm_vec_axpby.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double]
     lib.asm_vec_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     lib.asm_vec_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -463,6 +468,23 @@ class Context:
     def vec_dot(self, x, y):
         out = C.c_double()
         self._check(self.lib.asm_vec_dot(self.handle, x.ptr, y.ptr, C.byref(out)))
+        return out.value
+
+    def vec_multi_dot(self, w, vs):
+        """[w * v for v in vs] in one sweep over the vectors"""
+        n = len(vs)
+        ptrs = (C.c_void_p * max(n, 1))(*[v.ptr for v in vs])
+        out = (C.c_double * max(n, 1))()
+        self._check(self.lib.asm_vec_multi_dot(self.handle, w.ptr, ptrs, n, out))
+        return [out[i] for i in range(n)]
+
+    def vec_multi_axpy_norm(self, w, vs, a):
+        """w += sum_i a[i] vs[i]; returns w * w afterwards"""
+        n = len(vs)
+        ptrs = (C.c_void_p * max(n, 1))(*[v.ptr for v in vs])
+        coef = (C.c_double * max(n, 1))(*[float(x) for x in a])
+        out = C.c_double()
+        self._check(self.lib.asm_vec_multi_axpy_norm(self.handle, w.ptr, ptrs, coef, n, C.byref(out)))
         return out.value
 
     def vec_axpby(self, y, a, x, b):

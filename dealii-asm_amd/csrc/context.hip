@@ -352,14 +352,19 @@ namespace
     return ASM_OK;
   }
 
-  // global sum of a device scalar -> host
+  // global sum of up to 8 device scalars (d_scalar[0 .. n)) -> host
   int
-  reduce_scalar(asm_ctx *ctx, double *out)
+  reduce_scalar(asm_ctx *ctx, double *out, const int n = 1)
   {
     if (multi_rank(ctx))
       {
         if (ctx->loop)
           {
+            if (n != 1)
+              {
+                ctx->error = "loopback group: one scalar per reduction";
+                return ASM_ERR_NOT_SUPPORTED;
+              }
             LoopbackGroup &lg = *ctx->loop;
             HIP_TRY(hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -382,11 +387,12 @@ namespace
             HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_exchanged, 0));
             ctx->exchange_pending = false;
           }
-        NCCL_TRY(ncclAllReduce(ctx->d_scalar, ctx->d_scalar, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+        NCCL_TRY(ncclAllReduce(ctx->d_scalar, ctx->d_scalar, n, ncclDouble, ncclSum, ctx->comm, ctx->stream));
       }
-    HIP_TRY(hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_scalar, ctx->d_scalar, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *out = *ctx->h_scalar;
+    for (int i = 0; i < n; ++i)
+      out[i] = ctx->h_scalar[i];
     return ASM_OK;
   }
 
@@ -396,6 +402,56 @@ namespace
     HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
     vec_dot(ctx->g, x, y, ctx->d_scalar, ctx->stream);
     return reduce_scalar(ctx, out);
+  }
+
+  // out[i] = <w, v[i]>, i < n: w is read once per 8 vectors, one host synchronisation per 8 inner products
+  int
+  multi_dot(asm_ctx *ctx, const double *w, const double *const *v, const int n, double *out)
+  {
+    if (ctx->loop)
+      {
+        for (int i = 0; i < n; ++i)
+          if (const int err = dot(ctx, w, v[i], &out[i]))
+            return err;
+        return ASM_OK;
+      }
+    for (int c = 0; c < n; c += 8)
+      {
+        VecList L;
+        L.n = std::min(8, n - c);
+        for (int i = 0; i < 8; ++i)
+          {
+            L.v[i] = v[c + std::min(i, L.n - 1)];
+            L.a[i] = 0.;
+          }
+        HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, 8 * sizeof(double), ctx->stream));
+        vec_multi_dot(ctx->g, w, L, ctx->d_scalar, ctx->stream);
+        if (const int err = reduce_scalar(ctx, out + c, L.n))
+          return err;
+      }
+    return ASM_OK;
+  }
+
+  // w += sum_i a[i] v[i] (whole allocation), *norm2 = |w|^2 afterwards (owned DoFs, all ranks)
+  int
+  multi_axpy_norm(asm_ctx *ctx, double *w, const double *const *v, const double *a, const int n, double *norm2)
+  {
+    if (w == ctx->exchanged_vec)
+      ctx->exchanged_vec = nullptr;
+    HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
+    for (int c = 0; c < std::max(n, 1); c += 8)
+      {
+        VecList L;
+        L.n = std::max(0, std::min(8, n - c));
+        for (int i = 0; i < 8; ++i)
+          {
+            L.v[i] = L.n > 0 ? v[c + std::min(i, L.n - 1)] : w;
+            L.a[i] = (i < L.n) ? a[c + i] : 0.;
+          }
+        const bool last = c + 8 >= n;
+        vec_multi_axpy(ctx->g, w, L, ctx->s.n_alloc, last ? ctx->d_scalar : nullptr, ctx->stream);
+      }
+    return reduce_scalar(ctx, norm2);
   }
 
   // testing aid: the single-round ghost update through the loopback group (host-synchronous)
@@ -1566,6 +1622,32 @@ asm_vec_dot(asm_ctx *ctx, const double *x, const double *y, double *result)
 {
   const DeviceScope device_scope(ctx);
   return dot(ctx, x, y, result);
+}
+
+int
+asm_vec_multi_dot(asm_ctx *ctx, const double *w, const double *const *v, int32_t n, double *result)
+{
+  const DeviceScope device_scope(ctx);
+  if (n < 0 || (n > 0 && (v == nullptr || result == nullptr)))
+    {
+      ctx->error = "asm_vec_multi_dot: bad arguments";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  const int err = multi_dot(ctx, w, v, n, result);
+  return err ? err : launch_status(ctx, "asm_vec_multi_dot");
+}
+
+int
+asm_vec_multi_axpy_norm(asm_ctx *ctx, double *w, const double *const *v, const double *a, int32_t n, double *norm2)
+{
+  const DeviceScope device_scope(ctx);
+  if (n < 0 || norm2 == nullptr || (n > 0 && (v == nullptr || a == nullptr)))
+    {
+      ctx->error = "asm_vec_multi_axpy_norm: bad arguments";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  const int err = multi_axpy_norm(ctx, w, v, a, n, norm2);
+  return err ? err : launch_status(ctx, "asm_vec_multi_axpy_norm");
 }
 
 // elementwise updates also rewrite the ghost planes: a vector marked as exchanged stays consistent only

@@ -77,6 +77,16 @@ namespace asmamd
   void vec_invert_diagonal(double *d, long long n, hipStream_t st); // |d|>1e-10 ? 1/d : 1
   // reductions over the owned box; result[0] (device) accumulated, must be zeroed before
   void vec_dot(const DevGrid &g, const double *x, const double *y, double *result, hipStream_t st);
+  // up to 8 vectors of one Gram-Schmidt step: result[i] += <w, v[i]> (owned box); w += sum_i a[i] v[i] (whole allocation)
+  // with result[0] += |w_new|^2 over the owned box if result is given
+  struct VecList
+  {
+    const double *v[8];
+    double        a[8];
+    int           n;
+  };
+  void vec_multi_dot(const DevGrid &g, const double *w, const VecList &L, double *result, hipStream_t st);
+  void vec_multi_axpy(const DevGrid &g, double *w, const VecList &L, long long n_alloc, double *result, hipStream_t st);
   // deal.II set_initial_guess: v = (global lexicographic index % 11)
   void vec_initial_guess(const DevGrid &g, double *v, const long long gbegin[3], const long long gsize[3], hipStream_t st);
   // v(owned) += a

@@ -154,6 +154,85 @@ namespace asmamd
         }
     }
 
+    // result[i] += <w, L.v[i]> over the owned box, i < L.n <= 8: w is read once for all of them (the inner products of
+    // one Gram-Schmidt step)
+    __global__ void __launch_bounds__(VB)
+    multi_dot_kernel(const DevGrid g, const double *__restrict__ w, const VecList L, double *__restrict__ result)
+    {
+      const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+      double          s[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          int             I, J, K;
+          const long long o  = owned_offset(g, e, I, J, K);
+          const double    wv = w[o];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < L.n)
+              s[i] = fma(wv, L.v[i][o], s[i]);
+        }
+      __shared__ double part[8][VB / 64];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        {
+          double t = s[i];
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1)
+            t += __shfl_down(t, off, 64);
+          if ((threadIdx.x & 63) == 0)
+            part[i][threadIdx.x >> 6] = t;
+        }
+      __syncthreads();
+      if (threadIdx.x < L.n)
+        {
+          double t = 0.;
+          for (int q = 0; q < VB / 64; ++q)
+            t += part[threadIdx.x][q];
+          unsafeAtomicAdd(result + threadIdx.x, t);
+        }
+    }
+
+    // w += sum_i L.a[i] L.v[i] over the whole allocation; result (if given) += |w_new|^2 over the owned box
+    __global__ void __launch_bounds__(VB)
+    multi_axpy_kernel(const DevGrid g, double *__restrict__ w, const VecList L, const long long n_alloc, double *__restrict__ result)
+    {
+      double acc = 0.;
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n_alloc; e += (long long)gridDim.x * VB)
+        {
+          double t = w[e];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < L.n)
+              t = fma(L.a[i], L.v[i][e], t);
+          w[e] = t;
+          if (result != nullptr)
+            {
+              const long long K = e / g.stride[2], r = e - K * g.stride[2];
+              const long long J = r / g.stride[1], I = r - J * g.stride[1];
+              const bool own = I + g.ext_lo[0] >= 0 && I + g.ext_lo[0] <= g.own_hi[0] && J + g.ext_lo[1] >= 0 && J + g.ext_lo[1] <= g.own_hi[1] &&
+                               K + g.ext_lo[2] >= 0 && K + g.ext_lo[2] <= g.own_hi[2];
+              if (own)
+                acc = fma(t, t, acc);
+            }
+        }
+      if (result == nullptr)
+        return;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+      __shared__ double part[VB / 64];
+      if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          double t = 0.;
+          for (int q = 0; q < VB / 64; ++q)
+            t += part[q];
+          unsafeAtomicAdd(result, t);
+        }
+    }
+
     __global__ void __launch_bounds__(VB)
     initial_guess_kernel(const DevGrid g, double *__restrict__ v, const long long gb0, const long long gb1, const long long gb2,
                          const long long gs0, const long long gs1)
@@ -282,6 +361,17 @@ namespace asmamd
   {
     const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
     hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n, 8)), dim3(VB), 0, st, g, x, y, result);
+  }
+  void
+  vec_multi_dot(const DevGrid &g, const double *w, const VecList &L, double *result, hipStream_t st)
+  {
+    const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
+    hipLaunchKernelGGL(multi_dot_kernel, dim3(grid_for(n, 8)), dim3(VB), 0, st, g, w, L, result);
+  }
+  void
+  vec_multi_axpy(const DevGrid &g, double *w, const VecList &L, long long n_alloc, double *result, hipStream_t st)
+  {
+    hipLaunchKernelGGL(multi_axpy_kernel, dim3(grid_for(n_alloc, 8)), dim3(VB), 0, st, g, w, L, n_alloc, result);
   }
   void
   vec_initial_guess(const DevGrid &g, double *v, const long long gbegin[3], const long long gsize[3], hipStream_t st)

@@ -656,7 +656,7 @@ namespace
     res.converged        = beta <= tol;
     if (res.converged)
       return ASM_OK;
-    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m);
+    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 1), hneg(m + 1);
     int                 it = 0;
     while (it < sp.max_iterations)
       {
@@ -678,13 +678,16 @@ namespace
                 KS_CTX(asm_op_vmult(ctx, t, V[k]));
                 KS_TRY(apply_preconditioner(pc, error, V[k + 1], t));
               }
-            // classical Gram-Schmidt: all projections from the unmodified w
+            // classical Gram-Schmidt: all projections from the unmodified w, in one sweep over the basis; the
+            // subtraction and the norm of what is left in a second one
+            KS_CTX(asm_vec_multi_dot(ctx, V[k + 1], V.data(), k + 1, hcol.data()));
             for (int i = 0; i <= k; ++i)
-              KS_CTX(asm_vec_dot(ctx, V[k + 1], V[i], &H[(size_t)i * m + k]));
-            for (int i = 0; i <= k; ++i)
-              KS_CTX(asm_vec_axpby(ctx, V[k + 1], -H[(size_t)i * m + k], V[i], 1.));
+              {
+                H[(size_t)i * m + k] = hcol[i];
+                hneg[i]              = -hcol[i];
+              }
             double nn = 0.;
-            KS_CTX(asm_vec_dot(ctx, V[k + 1], V[k + 1], &nn));
+            KS_CTX(asm_vec_multi_axpy_norm(ctx, V[k + 1], V.data(), hneg.data(), k + 1, &nn));
             const double hk1 = std::sqrt(nn);
             H[(size_t)(k + 1) * m + k] = hk1;
             if (hk1 > 0.)
@@ -718,8 +721,10 @@ namespace
             y[i] = s / H[(size_t)i * m + i];
           }
         KS_CTX(asm_vec_zero(ctx, u));
-        for (int i = 0; i < k_done; ++i)
-          KS_CTX(asm_vec_axpby(ctx, u, y[i], V[i], 1.));
+        {
+          double unused = 0.;
+          KS_CTX(asm_vec_multi_axpy_norm(ctx, u, V.data(), y.data(), k_done, &unused));
+        }
         if (right)
           {
             KS_TRY(apply_preconditioner(pc, error, t, u));

@@ -262,6 +262,11 @@ int asm_compress_add(asm_ctx *ctx, double *v);
  * which keeps ghost values consistent), the inner product runs over the owned DoFs and is summed
  * over all ranks (synchronous: the value is returned to the host). */
 int asm_vec_dot(asm_ctx *ctx, const double *x, const double *y, double *result); /* x * y */
+/* One Gram-Schmidt step of SolverGMRES in two sweeps over the vectors (deal.II's solver_gmres.h does the same for
+ * LinearAlgebra::distributed::Vector: all inner products of a step in one pass, the subtraction and the norm of the
+ * result in a second one): result[i] = w * v[i];  w += sum_i a[i] v[i], *norm2 = w * w afterwards. */
+int asm_vec_multi_dot(asm_ctx *ctx, const double *w, const double *const *v, int32_t n, double *result);
+int asm_vec_multi_axpy_norm(asm_ctx *ctx, double *w, const double *const *v, const double *a, int32_t n, double *norm2);
 int asm_vec_axpby(asm_ctx *ctx, double *y, double a, const double *x, double b); /* y = a x + b y (sadd) */
 int asm_vec_scale(asm_ctx *ctx, double *y, double a, const double *x);           /* y = a x (equ); y may be x */
 int asm_vec_copy(asm_ctx *ctx, double *y, const double *x);                      /* y = x */

@@ -246,3 +246,22 @@ def test_direct_coarse_solver_refuses_large_levels(pkg):
     prm = fine_params(pkg, (13, 13, 13), 1, "dirichlet")
     with pytest.raises(Exception, match="direct coarse-grid solver"):
         pkg.Multigrid(prm, mg_type="h", coarse="direct")
+
+
+@pytest.mark.parametrize("n_vec", [1, 3, 8, 11])
+def test_gram_schmidt_sweeps(pkg, n_vec):
+    """asm_vec_multi_dot / asm_vec_multi_axpy_norm (one Gram-Schmidt step of GMRES in two sweeps) against numpy"""
+    with pkg.Context(fine_params(pkg, (6, 5, 4), 3, ["dirichlet", "neumann", "dirichlet"])) as c:
+        rng = np.random.default_rng(17)
+        wh = rng.standard_normal(c.n_dofs)
+        vh = [rng.standard_normal(c.n_dofs) for _ in range(n_vec)]
+        w, vs = c.vector(wh), [c.vector(v) for v in vh]
+        dots = c.vec_multi_dot(w, vs)
+        assert np.allclose(dots, [wh @ v for v in vh], rtol=1e-13, atol=1e-12)
+        a = rng.standard_normal(n_vec)
+        nn = c.vec_multi_axpy_norm(w, vs, a)
+        ref = wh + sum(ai * v for ai, v in zip(a, vh))
+        assert rel(w.get(), ref) < 1e-14
+        assert abs(nn - ref @ ref) < 1e-12 * (ref @ ref)
+        for v in [w] + vs:
+            v.free()
