@@ -47,7 +47,10 @@ namespace asmamd
     constexpr int N1  = 5;
     constexpr int NE  = 25;       // values per cell plane
     constexpr int WX  = 12;       // cells per wave (x)
-    constexpr int TY  = 8;        // cell rows per tile = waves per workgroup
+#ifndef ASM_TY
+#  define ASM_TY 8
+#endif
+    constexpr int TY  = ASM_TY;   // cell rows per tile = waves per workgroup
     constexpr int OX  = WX - 1;   // owned cells per tile, x
     constexpr int OY  = TY - 1;   // owned cells per tile, y
     constexpr int NT  = TY * 64;  // threads
@@ -983,7 +986,7 @@ namespace asmamd
     // FDM sweep
     // ---------------------------------------------------------------------------
     template <int MODE, bool HAS_PRE, bool HAS_POST, bool TENSOR>
-    __global__ void __launch_bounds__(NT, TY / 4)
+    __global__ void __launch_bounds__(NT, TY >= 8 ? TY / 4 : 2)
     fdm_tiled_kernel(const DevGrid g, const DevFdm f, const TiledArgs a, const Tiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1278,7 +1281,7 @@ namespace asmamd
     // data, and the same register choreography as the FDM sweep.
     // ---------------------------------------------------------------------------
     template <int MODE>
-    __global__ void __launch_bounds__(NT, TY / 4)
+    __global__ void __launch_bounds__(NT, TY >= 8 ? TY / 4 : 2)
     laplace_cart_tiled_kernel(const DevGrid g, const DevOp op, const TiledArgs a, const Tiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
