@@ -395,13 +395,23 @@ namespace asmamd
     fdm_gather_kernel(const DevGrid g, const DevFdm f, const FdmFused fu, const double *__restrict__ src, const double *__restrict__ tmp,
                       double *__restrict__ dst)
     {
-      const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1, sz = g.ext_hi[2] - g.ext_lo[2] + 1;
-      const long long n  = (long long)sx * sy * sz;
+      const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1;
       const int       m = f.m, m2 = m * m;
       const long long m3 = (long long)m2 * m;
-      for (long long e = blockIdx.x * (long long)BLOCK + threadIdx.x; e < n; e += (long long)gridDim.x * BLOCK)
+      // The DoFs of a z plane are taken in strips of H = 4 rows, x-major inside a strip (thread t of a strip: column t / 4,
+      // row t % 4): the rows of a patch result (m doubles) that consecutive DoF rows read lie next to each other in tmp,
+      // so the four rows of a strip share their cache lines inside one block; every XCD (own L2) takes a contiguous range
+      // of blocks, i.e. a slab of planes (blocks b and b + 8 share an XCD).
+      // (patches of fewer than 6 DoFs per direction: plain rows, measured faster there)
+      const int hs = f.m >= 6 ? 2 : 0, H = 1 << hs;
+      const int strip = H * sx, bpp = (((sy + H - 1) >> hs) * strip + BLOCK - 1) / BLOCK; // blocks per plane
+      {
+        const int       xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, nb = gridDim.x;
+        const long long b   = (long long)xcd * (nb >> 3) + min(xcd, nb & 7) + idx;
+        const int       sk = (int)(b / bpp), e2 = (int)(b % bpp) * BLOCK + threadIdx.x;
+        const int       t = e2 % strip, si = t >> hs, sj = H * (e2 / strip) + (t & (H - 1));
+        if (si < sx && sj < sy)
         {
-          const int si = (int)(e % sx), sj = (int)((e / sx) % sy), sk = (int)(e / ((long long)sx * sy));
           GatherDir cx, cy, cz;
           gather_candidates(g, f, 0, si + g.ext_lo[0], cx);
           gather_candidates(g, f, 1, sj + g.ext_lo[1], cy);
@@ -431,6 +441,7 @@ namespace asmamd
             }
           dst[off] = sum;
         }
+      }
     }
 
     // ---------------------------------------------------------------------
@@ -843,8 +854,9 @@ namespace asmamd
       }
     else
       hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, tmp);
-    const long long n = (long long)(g.ext_hi[0] - g.ext_lo[0] + 1) * (g.ext_hi[1] - g.ext_lo[1] + 1) * (g.ext_hi[2] - g.ext_lo[2] + 1);
-    const long long gb = std::min<long long>((n + BLOCK - 1) / BLOCK, 1 << 20);
+    const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1;
+    const int       H  = f.m >= 6 ? 4 : 1; // rows per strip, as in the kernel
+    const long long gb = (long long)((((sy + H - 1) / H) * H * sx + BLOCK - 1) / BLOCK) * (g.ext_hi[2] - g.ext_lo[2] + 1);
     hipLaunchKernelGGL(fdm_gather_kernel, dim3((unsigned)gb), dim3(BLOCK), 0, st, g, f, fu, src, tmp, dst);
   }
 

@@ -3,14 +3,14 @@
 # Runs `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` under rocprofv3 --pmc, one pass per
 # argument (counter collection only, no tracing), and prints the mean counter value per dispatch
 # of every sweep kernel variant that ran (ASM_TILED_ROWS=0 keeps the context from launching the other
-# Laplace variants while it tunes).
+# Laplace variants while it tunes).  PMC_BENCH_ARGS="--n-overlap 2 --degree 2" selects another workload.
 R=$PWD
 export ASM_BENCH_LAMBDA=1.7
 cd /tmp && export TMPDIR=/tmp
 i=0
 for c in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $c -d $R/gpurun_out/pmc_$i --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_$i.log; exit 1; }
+  rocprofv3 --pmc $c -d $R/gpurun_out/pmc_$i --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $PMC_BENCH_ARGS > $R/gpurun_out/pmc_$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_$i.log; exit 1; }
 done
 cd $R
 python3 - <<'PY'
@@ -19,7 +19,7 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob('gpurun_out/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'laplace_cart_tiled' not in k and 'fdm_tiled' not in k and 'laplace_generic' not in k and 'fdm_generic' not in k:
+        if not any(t in k for t in ('laplace_cart_tiled', 'fdm_tiled', 'laplace_generic', 'fdm_generic', 'fdm_gather', 'fdm_slice7')):
             continue
         # kernel name with its template arguments, without the parameter list (the context's tuning launches of
         # other kernel variants stay separate rows)
