@@ -72,6 +72,15 @@ namespace asmamd
     }
   };
 
+  // Blocks b and b + 8 of a launch are observed to land on the same XCD (own L2).  xcd_block maps the hardware block
+  // index to a work index such that every XCD takes a contiguous range of the work (a slab of the mesh): neighbouring
+  // cells / DoF rows, which share cache lines, then meet in one L2.  Placement only, never results.
+  ASM_HD long long xcd_block(const long long b, const long long n)
+  {
+    const long long xcd = b & 7, idx = b >> 3;
+    return xcd * (n >> 3) + (xcd < (n & 7) ? xcd : (n & 7)) + idx;
+  }
+
   enum PatchKind
   {
     PATCH_CELL   = 0, // element-centred, m = p - 1 + 2 n_overlap (matrix_free.h:90)

@@ -201,7 +201,8 @@ namespace asmamd
       const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
       // M = 7 with a slice-per-lane box (kernels_slice7.hip): this kernel takes the other cells, from a compact list
       const bool listed = M == 7 && STORE && f.s7_on;
-      const int  slot   = blockIdx.x * C::CPB + lc;
+      const int  blk    = (int)xcd_block(blockIdx.x, gridDim.x);
+      const int  slot   = blk * C::CPB + lc;
       const bool active = (lc < C::CPB) && (slot < (listed ? f.s7_n_others : ncells));
       const int  cell   = active ? (listed ? f.s7_others[slot] : slot) : 0;
 
@@ -231,7 +232,7 @@ namespace asmamd
       // Then its matrix is read with scalar loads instead of 49 LDS reads per line.
       int id0[3] = {0, 0, 0}, qmode[3] = {0, 0, 0};
       {
-        const int cell0 = listed ? f.s7_others[blockIdx.x * C::CPB] : blockIdx.x * C::CPB; // first cell of the block: exists
+        const int cell0 = listed ? f.s7_others[blk * C::CPB] : blk * C::CPB; // first cell of the block: exists
         const int c0[3] = {cell0 % g.nc[0], (cell0 / g.nc[0]) % g.nc[1], cell0 / (g.nc[0] * g.nc[1])};
         const int ce0   = (c0[0] + 1) + (g.nc[0] + 2) * ((c0[1] + 1) + (g.nc[1] + 2) * (c0[2] + 1));
 #pragma unroll
@@ -406,8 +407,7 @@ namespace asmamd
       const int hs = f.m >= 6 ? 2 : 0, H = 1 << hs;
       const int strip = H * sx, bpp = (((sy + H - 1) >> hs) * strip + BLOCK - 1) / BLOCK; // blocks per plane
       {
-        const int       xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, nb = gridDim.x;
-        const long long b   = (long long)xcd * (nb >> 3) + min(xcd, nb & 7) + idx;
+        const long long b = xcd_block(blockIdx.x, gridDim.x);
         const int       sk = (int)(b / bpp), e2 = (int)(b % bpp) * BLOCK + threadIdx.x;
         const int       t = e2 % strip, si = t >> hs, sj = H * (e2 / strip) + (t & (H - 1));
         if (si < sx && sj < sy)
@@ -607,6 +607,7 @@ namespace asmamd
       const int  lc     = tid / N2;
       const int  lt     = tid % N2;
       const int  ncells = g.nc[0] * g.nc[1] * g.nc[2];
+      // (no xcd_block here: with neighbouring cells on one XCD the scatter's atomics collide more, +12 % measured)
       const int  cell   = blockIdx.x * C::CPB + lc;
       const bool active = (lc < C::CPB) && (cell < ncells);
       if (tid < N2)

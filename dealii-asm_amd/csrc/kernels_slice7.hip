@@ -139,7 +139,7 @@ namespace asmamd
     {
       __shared__ double S_T[WPB * TB7];
       const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-      const long long gw = (long long)blockIdx.x * WPB + w; // wave index: (px, cy, cz)
+      const long long gw = xcd_block(blockIdx.x, gridDim.x) * WPB + w; // wave index: (px, cy, cz)
       const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
       if (gw >= n_waves)
         return; // no barrier in this kernel

@@ -56,7 +56,7 @@ namespace asmamd
     {
       constexpr int M2 = M * M, M3 = M * M * M, E = M2 + M;
       const long long ncells = (long long)g.nc[0] * g.nc[1] * g.nc[2];
-      const long long cell   = blockIdx.x * (long long)BLOCK + threadIdx.x;
+      const long long cell   = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
       if (cell >= ncells)
         return;
       const int c3[3] = {(int)(cell % g.nc[0]), (int)((cell / g.nc[0]) % g.nc[1]), (int)(cell / ((long long)g.nc[0] * g.nc[1]))};
@@ -165,7 +165,7 @@ namespace asmamd
     {
       constexpr int N = P + 1, N3 = N * N * N;
       const long long ncells = (long long)g.nc[0] * g.nc[1] * g.nc[2];
-      const long long cell   = blockIdx.x * (long long)BLOCK + threadIdx.x;
+      const long long cell   = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
       if (cell >= ncells)
         return;
       const int c3[3] = {(int)(cell % g.nc[0]), (int)((cell / g.nc[0]) % g.nc[1]), (int)(cell / ((long long)g.nc[0] * g.nc[1]))};
