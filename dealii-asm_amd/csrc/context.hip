@@ -1267,21 +1267,22 @@ asm_create(const asm_params *p, asm_ctx **out)
           if (ok)
             {
               const int           m = 7, E = m * m + m;
+              // in the order the slice kernel scales in: [x index a][z index c][y index b]
               std::vector<double> inv((size_t)m * m * m);
-              for (int c = 0; c < m; ++c)
-                for (int b = 0; b < m; ++b)
-                  for (int a = 0; a < m; ++a)
-                    inv[(c * m + b) * m + a] = 1.0 / (s.eig[(size_t)f.s7_inst[0] * E + m * m + a] +
+              for (int a = 0; a < m; ++a)
+                for (int c = 0; c < m; ++c)
+                  for (int b = 0; b < m; ++b)
+                    inv[(a * m + c) * m + b] = 1.0 / (s.eig[(size_t)f.s7_inst[0] * E + m * m + a] +
                                                       (s.eig[(size_t)f.s7_inst[1] * E + m * m + b] + s.eig[(size_t)f.s7_inst[2] * E + m * m + c]));
               UP(inv, &f.s7_inv);
               for (int k = 0; k < 2; ++k)
                 {
-                  const std::vector<double> &wx = k == 0 ? s.w_pre[0] : s.w_post[0], &wy = k == 0 ? s.w_pre[1] : s.w_post[1];
-                  std::vector<double>        wxy(49);
-                  for (int j = 0; j < 7; ++j)
-                    for (int i = 0; i < 7; ++i)
-                      wxy[j * 7 + i] = wx[(f.s7_lo[0] + 1) * 7 + i] * wy[(f.s7_lo[1] + 1) * 7 + j];
-                  UP(wxy, &f.s7_wxy[k]);
+                  const std::vector<double> &wy = k == 0 ? s.w_pre[1] : s.w_post[1], &wz = k == 0 ? s.w_pre[2] : s.w_post[2];
+                  std::vector<double>        wyz(49);
+                  for (int kk = 0; kk < 7; ++kk)
+                    for (int j = 0; j < 7; ++j)
+                      wyz[kk * 7 + j] = wy[(f.s7_lo[1] + 1) * 7 + j] * wz[(f.s7_lo[2] + 1) * 7 + kk];
+                  UP(wyz, &f.s7_wyz[k]);
                 }
               std::vector<int> others;
               for (int cz = 0; cz < s.g.nc[2]; ++cz)

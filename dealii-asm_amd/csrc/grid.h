@@ -108,8 +108,8 @@ namespace asmamd
     // direction is solved by the slice-per-lane kernel (kernels_slice7.hip), the generic kernel skips it
     int           s7_on;
     int           s7_lo[3], s7_hi[3], s7_inst[3];
-    const double *s7_inv;    // [c][b][a] reciprocal eigenvalue sums of that instance triple
-    const double *s7_wxy[2]; // [j][i] products of the x and y weight factors of the box's cells (pre, post)
+    const double *s7_inv;    // [a][c][b] (x, z, y eigen-index) reciprocal eigenvalue sums of that instance triple
+    const double *s7_wyz[2]; // [k][j] products of the z and y weight factors of the box's cells (pre, post)
     const int *   s7_others; // the cells outside the box (linear index), for the generic kernel
     int           s7_n_others;
     int           small;     // m <= 3: one thread per cell, the patch in registers (kernels_small.hip)

@@ -155,73 +155,67 @@ namespace asmamd
 
       const int o0 = f.origin_mul * cx + f.origin_add, o1 = f.origin_mul * cy + f.origin_add, o2 = f.origin_mul * cz + f.origin_add;
       // every DoF of a region patch exists (the region's cells have both neighbours in every direction)
-      const long long zoff = g.store_index_near(2, o2 + sub) * g.stride[2];
-      const int       x0   = g.store_index_near(0, o0);
-      const bool      xcont = g.store_index_near(0, o0 + M - 1) == x0 + M - 1; // no periodic seam inside the row
+      // Orientation: the 7 lanes of a patch are its x indices, the registers v[k*7 + j] its (z, y) plane - the lanes of a
+      // patch then read 7 consecutive DoFs of src and write 7 consecutive entries of tmp with every instruction (with the
+      // lanes along z, as in round 2's first version, every lane touched its own 64-byte sector).
+      const long long xoff = g.store_index_near(0, o0 + sub);
+      long long       yoff[M];
+#pragma unroll
+      for (int jj = 0; jj < M; ++jj)
+        yoff[jj] = g.store_index_near(1, o1 + jj) * g.stride[1];
 
       double v[M2];
-      // ---- gather: layout A, lane = z plane `sub`, v[j*7 + i]
+      // ---- gather: layout A, lane = x index `sub`, v[k*7 + j]
 #pragma unroll
-      for (int j = 0; j < M; ++j)
+      for (int k = 0; k < M; ++k)
         {
-          const double *row = src + zoff + g.store_index_near(1, o1 + j) * g.stride[1];
-          if (xcont)
-            {
+          const double *plane = src + xoff + g.store_index_near(2, o2 + k) * g.stride[2];
 #pragma unroll
-              for (int i = 0; i < M; ++i)
-                v[j * M + i] = row[x0 + i];
-            }
-          else
-            {
-#pragma unroll
-              for (int i = 0; i < M; ++i)
-                v[j * M + i] = row[g.store_index_near(0, o0 + i)];
-            }
+          for (int jj = 0; jj < M; ++jj)
+            v[k * M + jj] = plane[yoff[jj]];
         }
       if (HAS_PRE)
         {
-          // the rows of weight factors are the same for every cell of the region: their x-y products are scalar
-          // operands, the z factor belongs to the lane's plane
-          const UniformMatrix7 wxy(f.s7_wxy[0]);
-          const double         wz = f.w_pre[2][(sa.lo[2] + 1) * M + sub];
+          // the rows of weight factors are the same for every cell of the region: their y-z products are scalar
+          // operands, the x factor belongs to the lane
+          const UniformMatrix7 wyz(f.s7_wyz[0]);
+          const double         wx = f.w_pre[0][(sa.lo[0] + 1) * M + sub];
 #pragma unroll
           for (int e = 0; e < M2; ++e)
-            v[e] = (v[e] * wxy[e]) * wz;
+            v[e] = (v[e] * wyz[e]) * wx;
         }
       const UniformMatrix7 Qx(sa.qx), Qy(sa.qy), Qz(sa.qz);
-      sweep_fast7<true>(v, Qx);  // i -> a
-      sweep_slow7<true>(v, Qy);  // j -> b
-      transpose7(v, Tw, lane, cl, sub); // layout B: lane = b, v[k*7 + a]
+      sweep_fast7<true>(v, Qy);  // j -> b
       sweep_slow7<true>(v, Qz);  // k -> c
+      transpose7(v, Tw, lane, cl, sub); // layout B: lane = c, v[i*7 + b]
+      sweep_slow7<true>(v, Qx);  // i -> a
       {
-        const double *inv = sa.inv + sub * M; // [c][b = sub][a]
+        const double *inv = sa.inv + sub * M; // [a][c = sub][b]
 #pragma unroll
-        for (int c = 0; c < M; ++c)
+        for (int a = 0; a < M; ++a)
 #pragma unroll
-          for (int a = 0; a < M; ++a)
-            v[c * M + a] *= inv[c * M2 + a];
+          for (int b = 0; b < M; ++b)
+            v[a * M + b] *= inv[a * M2 + b];
       }
+      sweep_slow7<false>(v, Qx);
+      transpose7(v, Tw, lane, cl, sub); // layout A: lane = i, v[c*7 + b]
       sweep_slow7<false>(v, Qz);
-      transpose7(v, Tw, lane, cl, sub); // layout A: lane = k, v[b*7 + a]
-      sweep_slow7<false>(v, Qy);
-      sweep_fast7<false>(v, Qx);
+      sweep_fast7<false>(v, Qy);
       if (HAS_POST)
         {
-          // the rows of weight factors are the same for every cell of the region: their x-y products are scalar
-          // operands, the z factor belongs to the lane's plane
-          const UniformMatrix7 wxy(f.s7_wxy[1]);
-          const double         wz = f.w_post[2][(sa.lo[2] + 1) * M + sub];
+          const UniformMatrix7 wyz(f.s7_wyz[1]);
+          const double         wx = f.w_post[0][(sa.lo[0] + 1) * M + sub];
 #pragma unroll
           for (int e = 0; e < M2; ++e)
-            v[e] = (v[e] * wxy[e]) * wz;
+            v[e] = (v[e] * wyz[e]) * wx;
         }
       if (active)
         {
           const long long cell = cx + (long long)g.nc[0] * (cy + (long long)g.nc[1] * cz);
-          double *        out  = tmp + cell * M3 + sub * M2;
+          double *        out  = tmp + cell * M3 + sub; // tmp[cell][k][j][i]
 #pragma unroll
           for (int e = 0; e < M2; ++e)
-            out[e] = v[e];
+            out[e * M] = v[e];
         }
     }
   } // namespace
