@@ -398,7 +398,7 @@ namespace asmamd
     {
       const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1;
       const int       m = f.m, m2 = m * m;
-      const long long m3 = (long long)m2 * m;
+      const long long m3 = (long long)m2 * m, ncells = (long long)g.nc[0] * g.nc[1] * g.nc[2];
       // The DoFs of a z plane are taken in strips of H = 4 rows, x-major inside a strip (thread t of a strip: column t / 4,
       // row t % 4): the rows of a patch result (m doubles) that consecutive DoF rows read lie next to each other in tmp,
       // so the four rows of a strip share their cache lines inside one block; every XCD (own L2) takes a contiguous range
@@ -422,7 +422,11 @@ namespace asmamd
               for (int kx = 0; kx < cx.n; ++kx)
                 {
                   const long long cell = cx.cell[kx] + (long long)g.nc[0] * (cy.cell[ky] + (long long)g.nc[1] * cz.cell[kz]);
-                  sum += tmp[cell * m3 + cz.idx[kz] * m2 + cy.idx[ky] * m + cx.idx[kx]];
+                  {
+                    const long long local = cz.idx[kz] * m2 + cy.idx[ky] * m + cx.idx[kx];
+                    // (the per-cell kernels store entry-major, tmp[entry][cell]: consecutive cells next to each other)
+                    sum += f.small ? tmp[local * ncells + cell] : tmp[cell * m3 + local];
+                  }
                 }
           const long long off = si * g.stride[0] + sj * g.stride[1] + sk * g.stride[2];
           if (fu.mode != PC_PLAIN)

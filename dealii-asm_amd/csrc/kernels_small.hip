@@ -129,7 +129,7 @@ namespace asmamd
               const double w  = f.w_post[0][(c3[0] + 1) * M + i] * f.w_post[1][(c3[1] + 1) * M + j] * f.w_post[2][(c3[2] + 1) * M + k];
               const bool   ok = ex[0][i] && ex[1][j] && ex[2][k] && w != 0.;
               if (STORE)
-                dst[cell * M3 + (k * M + j) * M + i] = ok ? u[(k * M + j) * M + i] * w : 0.;
+                dst[((k * M + j) * M + i) * ncells + cell] = ok ? u[(k * M + j) * M + i] * w : 0.; // tmp[entry][cell]
               else if (ok)
                 unsafeAtomicAdd(&dst[off[0][i] + off[1][j] + off[2][k]], u[(k * M + j) * M + i] * w);
             }
