@@ -807,17 +807,25 @@ namespace asmamd
           __syncthreads();
           if (active)
             {
-              // thread (j=b, i=a): column along z
+              // thread (j=b, i=a): column along z.  The cells of a block are consecutive in x: the last column of a cell
+              // and the first one of the next cell of the block are the same DoFs - the right cell adds its neighbour's
+              // column from LDS, the left one skips those atomics: a fifth fewer at degree 4, and no back-to-back updates of
+              // one address by neighbouring threads, which serialise in the L2 (80^3 Cartesian cells: 0.94 -> 0.53 ms,
+              // 78^3 deformed cells 0.86 -> 0.77 ms; a 5 x 2 tile of cells with x and y merges was slower again: 0.63 / 0.83)
+              const bool take_left  = !DIAG && a == 0 && lc > 0 && c3[0] > 0;
+              const bool give_right = !DIAG && a == P && lc + 1 < C::CPB && cell + 1 < ncells && c3[0] + 1 < g.nc[0];
 #pragma unroll
               for (int k = 0; k < N1; ++k)
                 {
-                  const double v = T0[lc][k * N2 + b * N1 + a];
+                  double v = T0[lc][k * N2 + b * N1 + a];
+                  if (take_left)
+                    v += T0[lc - 1][k * N2 + b * N1 + P];
                   if (DIAG)
                     {
                       if (k * N2 + lt == col)
                         diag_acc[k] = v;
                     }
-                  else if (valid[k])
+                  else if (valid[k] && !give_right)
                     unsafeAtomicAdd(&dst[off[k]], sign * v);
                 }
             }
