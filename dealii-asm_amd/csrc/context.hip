@@ -72,6 +72,7 @@ struct asm_ctx
   DevFdm                   f;
   DevOp                    op;
   std::vector<void *>      allocs;
+  bool                     ras_direct = true; // ASM_RAS_ATOMICS: restricted additive Schwarz through the atomics path on one rank too
   std::vector<double *>    work_pool; // released solver work vectors (asm_work_vector_*), kept until asm_destroy
   long long                data_bytes = 0;
   double *                 inv_diag   = nullptr;
@@ -702,6 +703,28 @@ namespace
           }
         return ASM_OK;
       }
+    if (ctx->patch_tmp == nullptr && !multi_rank(ctx) && ctx->s.prm.weighting_type == ASM_W_RAS && ctx->s.prm.element_centric != 0 &&
+        ctx->ras_direct)
+      {
+        // restricted additive Schwarz on element-centred patches, one rank: every DoF is written by exactly one patch,
+        // which stores the updated value itself (no zeroing, no atomics, no update passes)
+        fu.mode   = mode;
+        fu.x      = x;
+        fu.x_old  = x_old;
+        fu.f1     = f1;
+        fu.f2     = f2;
+        fu.direct = 1;
+        prof_mark(ctx, 1, true);
+        const bool ok = fdm_generic(ctx->g, ctx->f, src, dst, nullptr, fu, ctx->stream);
+        prof_mark(ctx, 1, false);
+        if (!ok)
+          {
+            ctx->error = "generic FDM kernel not available for this patch size";
+            return ASM_ERR_NOT_SUPPORTED;
+          }
+        vec_constrained_fused(ctx->g, fu, dst, src, ctx->stream);
+        return ASM_OK;
+      }
     double *t = (mode == PC_PLAIN) ? dst : ctx->T;
     if (ctx->patch_tmp == nullptr)
       HIP_TRY(hipMemsetAsync(t, 0, n * sizeof(double), ctx->stream));
@@ -1308,6 +1331,7 @@ asm_create(const asm_params *p, asm_ctx **out)
   ctx->allocs.push_back(ctx->S);
   // (restricted additive Schwarz keeps the atomics: only a patch's own DoFs have a non-zero weight,
   // so a sixth of the entries is added and the atomic form is the faster one - measured)
+  ctx->ras_direct = std::getenv("ASM_RAS_ATOMICS") == nullptr;
   if (s.prm.precond_type == ASM_PRECOND_FDM && !s.fdm_tiled && s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_FDM_ATOMICS") == nullptr)
     {
       // patch results of the generic FDM sweep; without it (allocation failure) the sweep adds with atomics

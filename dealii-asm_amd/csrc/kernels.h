@@ -18,6 +18,10 @@ namespace asmamd
     int           mode = 2; // PC_PLAIN
     const double *x = nullptr, *x_old = nullptr;
     double        f1 = 0., f2 = 1.;
+    // without tmp: 1 = every DoF has exactly one patch with a non-zero weight (restricted additive Schwarz on
+    // element-centred patches, one rank): the patch kernel stores the updated value itself - no zeroing, no atomics,
+    // no update passes; constrained DoFs are set by vec_constrained_fused afterwards
+    int direct = 0;
   };
   bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, const FdmFused &fu, hipStream_t st);
   // kernels_slice7.hip: the patch solves of the box f.s7_* into tmp[cell][343] (false: not applicable)
@@ -93,6 +97,8 @@ namespace asmamd
   void vec_add_scalar_owned(const DevGrid &g, double *v, double a, hipStream_t st);
   // Dirichlet planes: mode 0: dst = 0 ; 1: dst = src ; 2: dst = b - x
   void vec_constrained(const DevGrid &g, int mode, double *dst, const double *src, const double *b, hipStream_t st);
+  // Dirichlet planes: dst = the fused update of FdmFused applied to the unit row, i.e. with P^-1 src replaced by src (0 for PC_PLAIN)
+  void vec_constrained_fused(const DevGrid &g, const FdmFused &fu, double *dst, const double *src, hipStream_t st);
   // box copy between a packed buffer and a vector (halo exchange, import/export)
   // mode 0: buf <- vec ; 1: vec <- buf ; 2: vec += buf ; 3: vec <- 0
   void vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st);

@@ -189,7 +189,7 @@ namespace asmamd
     //                entry does not contribute) and fdm_gather_kernel sums the patches per DoF
     template <int M, bool STORE>
     __global__ void __launch_bounds__(BLOCK)
-    fdm_generic_kernel(const DevGrid g, const DevFdm f, const double *__restrict__ src, double *__restrict__ dst)
+    fdm_generic_kernel(const DevGrid g, const DevFdm f, const FdmFused fu, const double *__restrict__ src, double *__restrict__ dst)
     {
       using C = FdmCfg<M>;
       __shared__ double T[C::CPB][C::M3];
@@ -355,7 +355,28 @@ namespace asmamd
                   const int    K = o2 + k;
                   const double w = wxy * f.w_post[2][(c3[2] + 1) * M + k];
                   if (g.exists(2, K) && w != 0.)
-                    unsafeAtomicAdd(&dst[base + g.store_index(2, K) * g.stride[2]], u[k] * w);
+                    {
+                      const long long o = base + g.store_index(2, K) * g.stride[2];
+                      if (!fu.direct)
+                        unsafeAtomicAdd(&dst[o], u[k] * w);
+                      else if (!(g.dirichlet(0, I) || g.dirichlet(1, J) || g.dirichlet(2, K)))
+                        {
+                          // (constrained DoFs are left alone: vec_constrained_fused sets them from the unit row and must
+                          //  still find x_old there when dst is x_old)
+                          // the only patch that contributes to this DoF: store the updated value (FdmFused::direct)
+                          double t = u[k] * w;
+                          if (fu.mode == PC_FIRST)
+                            t = fu.f2 * t;
+                          else if (fu.mode == PC_STEP1)
+                            t = fu.f1 * fu.x[o] + fu.f2 * t;
+                          else if (fu.mode == PC_UPDATE)
+                            {
+                              const double xv = fu.x[o];
+                              t               = xv + fu.f1 * (xv - fu.x_old[o]) + fu.f2 * t;
+                            }
+                          dst[o] = t;
+                        }
+                    }
                 }
             }
         }
@@ -852,8 +873,8 @@ namespace asmamd
     const int blocks = (ncells + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
     if (tmp == nullptr)
       {
-        if (!(M <= 3 && f.small && fdm_cell(g, f, src, dst, false, st)))
-          hipLaunchKernelGGL((fdm_generic_kernel<M, false>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, dst);
+        if (fu.direct || !(M <= 3 && f.small && fdm_cell(g, f, src, dst, false, st)))
+          hipLaunchKernelGGL((fdm_generic_kernel<M, false>), dim3(blocks), dim3(BLOCK), 0, st, g, f, fu, src, dst);
         return;
       }
     if (M <= 3 && f.small && fdm_cell(g, f, src, tmp, true, st))
@@ -862,11 +883,11 @@ namespace asmamd
       {
         const int others = (f.s7_n_others + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
         if (others > 0)
-          hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(others), dim3(BLOCK), 0, st, g, f, src, tmp);
+          hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(others), dim3(BLOCK), 0, st, g, f, fu, src, tmp);
         fdm_slice7(g, f, src, tmp, st);
       }
     else
-      hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(blocks), dim3(BLOCK), 0, st, g, f, src, tmp);
+      hipLaunchKernelGGL((fdm_generic_kernel<M, true>), dim3(blocks), dim3(BLOCK), 0, st, g, f, fu, src, tmp);
     const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1;
     const int       H  = f.m >= 6 ? 4 : 1; // rows per strip, as in the kernel
     const long long gb = (long long)((((sy + H - 1) / H) * H * sx + BLOCK - 1) / BLOCK) * (g.ext_hi[2] - g.ext_lo[2] + 1);

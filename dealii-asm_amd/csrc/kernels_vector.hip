@@ -284,6 +284,47 @@ namespace asmamd
     }
 
     __global__ void __launch_bounds__(VB)
+    constrained_fused_kernel(const DevGrid g, const FdmFused fu, double *__restrict__ dst, const double *__restrict__ src)
+    {
+      const int face = blockIdx.y; // 2*d + side
+      const int d = face / 2, side = face % 2;
+      if (!(side ? g.dir_hi[d] : g.dir_lo[d]))
+        return;
+      const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+      const int lo1 = g.wrap[d1] ? 0 : g.ext_lo[d1], n1 = (g.wrap[d1] ? g.nc[d1] * g.p - 1 : g.ext_hi[d1]) - lo1 + 1;
+      const int lo2 = g.wrap[d2] ? 0 : g.ext_lo[d2], n2 = (g.wrap[d2] ? g.nc[d2] * g.p - 1 : g.ext_hi[d2]) - lo2 + 1;
+      const long long n = (long long)n1 * n2;
+      for (long long e = blockIdx.x * (long long)VB + threadIdx.x; e < n; e += (long long)gridDim.x * VB)
+        {
+          int c[3];
+          c[d]  = side ? g.nc[d] * g.p : 0;
+          c[d1] = lo1 + (int)(e % n1);
+          c[d2] = lo2 + (int)(e / n1);
+          // a DoF on an edge or a corner lies on two or three of the planes: the update is not idempotent when dst is
+          // x_old, so only the plane of the lowest direction takes it
+          bool earlier = false;
+          for (int dd = 0; dd < d; ++dd)
+            earlier = earlier || g.dirichlet(dd, c[dd]);
+          if (earlier)
+            continue;
+          const long long o = g.offset(c[0], c[1], c[2]);
+          double          t = src[o];
+          if (fu.mode == PC_PLAIN)
+            t = 0.;
+          else if (fu.mode == PC_FIRST)
+            t = fu.f2 * t;
+          else if (fu.mode == PC_STEP1)
+            t = fu.f1 * fu.x[o] + fu.f2 * t;
+          else
+            {
+              const double xv = fu.x[o];
+              t               = xv + fu.f1 * (xv - fu.x_old[o]) + fu.f2 * t;
+            }
+          dst[o] = t;
+        }
+    }
+
+    __global__ void __launch_bounds__(VB)
     box_kernel(const DevGrid g, const int mode, double *__restrict__ vec, double *__restrict__ buf, const int l0, const int l1,
                const int l2, const int s0, const int s1, const int s2)
     {
@@ -395,6 +436,16 @@ namespace asmamd
     if (!any)
       return;
     hipLaunchKernelGGL(constrained_kernel, dim3(64, 6), dim3(VB), 0, st, g, mode, dst, src, b);
+  }
+  void
+  vec_constrained_fused(const DevGrid &g, const FdmFused &fu, double *dst, const double *src, hipStream_t st)
+  {
+    bool any = false;
+    for (int d = 0; d < 3; ++d)
+      any = any || g.dir_lo[d] || g.dir_hi[d];
+    if (!any)
+      return;
+    hipLaunchKernelGGL(constrained_fused_kernel, dim3(64, 6), dim3(VB), 0, st, g, fu, dst, src);
   }
   void
   vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st)

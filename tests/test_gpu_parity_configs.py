@@ -142,6 +142,36 @@ def test_chebyshev_p7_ras_config5(pkg):
         assert rel(xv.get(), cheb.step(x0, b)) < TOL
 
 
+@pytest.mark.parametrize("p,nc,geometry,n_overlap", [(4, (6, 4, 4), "cartesian", 2), (4, (6, 2, 2), "kershaw", 2), (3, (4, 4, 4), "cartesian", 1), (2, (6, 6, 4), "cartesian", 2)])
+def test_ras_direct_store_equals_atomics(pkg, monkeypatch, p, nc, geometry, n_overlap):
+    """restricted additive Schwarz on one rank: the patch kernel that stores the updated values itself (every DoF has
+    exactly one contributing patch) against the zero + atomics + update passes form (ASM_RAS_ATOMICS), both against the oracle"""
+    out = []
+    rng = np.random.default_rng(13)
+    for atomics in (False, True):
+        if atomics:
+            monkeypatch.setenv("ASM_RAS_ATOMICS", "1")
+        mesh, ctx = make_pair(pkg, nc, p, ["dirichlet", "neumann", "dirichlet"], geometry, eps=(0.3, 0.3), n_overlap=n_overlap,
+                              weighting="ras", cheb_degree=3)
+        with ctx:
+            if not out:
+                b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+                op = orc.LaplaceOperator(mesh)
+                cheb = orc.Chebyshev(op, orc.ASPoissonPreconditioner(mesh, n_overlap, "ras"), degree=3, lambda_max=1.5)
+                ref = (cheb.vmult(b), cheb.step(x0, b))
+            ctx.set_eigenvalue(1.5)
+            bv, xv, yv = ctx.vector(b), ctx.vector(), ctx.vector()
+            ctx.precond_vmult(yv, bv)
+            ctx.cheb_vmult(xv, bv)
+            r1 = xv.get()
+            xv.set(x0)
+            ctx.cheb_step(xv, bv)
+            out.append((yv.get(), r1, xv.get()))
+    for k in range(3):
+        assert rel(out[0][k], out[1][k]) < TOL
+    assert rel(out[0][1], ref[0]) < TOL and rel(out[0][2], ref[1]) < TOL
+
+
 # ---------------------------------------------------------------------------
 # the bench workload at full size against the threaded C++ restatement (itself checked against the
 # numpy oracle in tests/test_oracle_cpu_port.py)
