@@ -1322,6 +1322,42 @@ asm_create(const asm_params *p, asm_ctx **out)
               f.s7_on = 1;
             }
         }
+      // 7^3 patches on a mesh without tensor-product structure (deformed cells): the box of cells all of whose patch DoFs
+      // exist goes to the per-cell-matrix variant of the slice-per-lane kernel
+      if (!s.tensor_inst && s.m == 7 && !s.fdm_tiled && s.prm.world_size == 1 && std::getenv("ASM_NO_SLICE7") == nullptr)
+        {
+          bool ok = true;
+          for (int d = 0; d < 3; ++d)
+            {
+              int lo = 0, hi = s.g.nc[d] - 1;
+              while (lo <= hi && f.origin_mul * lo + f.origin_add < s.g.ext_lo[d])
+                ++lo;
+              while (hi >= lo && f.origin_mul * hi + f.origin_add + 6 > s.g.ext_hi[d])
+                --hi;
+              f.s7_lo[d]   = lo;
+              f.s7_hi[d]   = hi + 1;
+              f.s7_inst[d] = 0;
+              ok           = ok && hi >= lo;
+            }
+          if (ok)
+            {
+              std::vector<int> others;
+              for (int cz = 0; cz < s.g.nc[2]; ++cz)
+                for (int cy = 0; cy < s.g.nc[1]; ++cy)
+                  for (int cx = 0; cx < s.g.nc[0]; ++cx)
+                    if (!(cx >= f.s7_lo[0] && cx < f.s7_hi[0] && cy >= f.s7_lo[1] && cy < f.s7_hi[1] && cz >= f.s7_lo[2] && cz < f.s7_hi[2]))
+                      others.push_back(cx + s.g.nc[0] * (cy + s.g.nc[1] * cz));
+              f.s7_n_others = (int)others.size();
+              f.s7_others   = nullptr;
+              if (!others.empty())
+                {
+                  UP(others, &f.s7_others);
+                }
+              f.s7_inv = nullptr;
+              f.s7_wyz[0] = f.s7_wyz[1] = nullptr;
+              f.s7_on     = 2;
+            }
+        }
     }
 #undef UP
   if (alloc_vec(ctx, &ctx->R) || alloc_vec(ctx, &ctx->T) || alloc_vec(ctx, &ctx->S))

@@ -106,7 +106,7 @@ namespace asmamd
     const double *w_post[3]; // [nc[d]][m] 1-D factors of the post weight, or nullptr
     // m = 7 on tensor-product meshes: the box of cells [s7_lo, s7_hi) that share one parity-sorted instance per
     // direction is solved by the slice-per-lane kernel (kernels_slice7.hip), the generic kernel skips it
-    int           s7_on;
+    int           s7_on; // 0: no; 1: one instance triple for the whole box (tensor meshes); 2: per-cell instances (deformed meshes)
     int           s7_lo[3], s7_hi[3], s7_inst[3];
     const double *s7_inv;    // [a][c][b] (x, z, y eigen-index) reciprocal eigenvalue sums of that instance triple
     const double *s7_wyz[2]; // [k][j] products of the z and y weight factors of the box's cells (pre, post)

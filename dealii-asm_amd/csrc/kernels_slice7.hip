@@ -218,6 +218,161 @@ namespace asmamd
             out[e * M] = v[e];
         }
     }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // The same register layout for meshes WITHOUT tensor-product structure (deformed cells: every cell has its own three
+    // 1-D eigen-decompositions, include/matrix_free.h:1023-1162 with one TensorProductMatrixSymmetricSum per cell): the
+    // 7 x 7 matrix of the direction being swept is held in registers by the 7 lanes of the patch (one copy per lane, the
+    // loads of a patch's lanes coalesce), full 7-point lines (no parity structure), reciprocal eigenvalue sums computed
+    // on the fly.  Five matrix loads per patch (the x matrix serves its forward and backward sweep).
+    // ---------------------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ void
+    load_matrix7(double (&q)[M2], const double *__restrict__ p)
+    {
+#pragma unroll
+      for (int e = 0; e < M2; ++e)
+        q[e] = p[e];
+    }
+    // line: out[a] = sum_i Q[i][a] in[i] (FWD) / out[i] = sum_a Q[i][a] in[a]
+    template <bool FWD>
+    __device__ __forceinline__ void
+    line7_reg(double &u0, double &u1, double &u2, double &u3, double &u4, double &u5, double &u6, const double (&Q)[M2])
+    {
+      const double in[M] = {u0, u1, u2, u3, u4, u5, u6};
+      double       out[M];
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+        {
+          double t = (FWD ? Q[a] : Q[a * M]) * in[0];
+#pragma unroll
+          for (int i = 1; i < M; ++i)
+            t = fma(FWD ? Q[i * M + a] : Q[a * M + i], in[i], t);
+          out[a] = t;
+        }
+      u0 = out[0];
+      u1 = out[1];
+      u2 = out[2];
+      u3 = out[3];
+      u4 = out[4];
+      u5 = out[5];
+      u6 = out[6];
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void
+    sweep_fast7_reg(double (&v)[M2], const double (&Q)[M2])
+    {
+#pragma unroll
+      for (int s = 0; s < M; ++s)
+        line7_reg<FWD>(v[s * M + 0], v[s * M + 1], v[s * M + 2], v[s * M + 3], v[s * M + 4], v[s * M + 5], v[s * M + 6], Q);
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void
+    sweep_slow7_reg(double (&v)[M2], const double (&Q)[M2])
+    {
+#pragma unroll
+      for (int f = 0; f < M; ++f)
+        line7_reg<FWD>(v[0 * M + f], v[1 * M + f], v[2 * M + f], v[3 * M + f], v[4 * M + f], v[5 * M + f], v[6 * M + f], Q);
+    }
+
+    template <bool HAS_PRE, bool HAS_POST>
+    __global__ void __launch_bounds__(WPB * 64, 2)
+    fdm_slice7_cell_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const double *__restrict__ src, double *__restrict__ tmp)
+    {
+      __shared__ double S_T[WPB * TB7];
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      const long long gw = xcd_block(blockIdx.x, gridDim.x) * WPB + w; // wave index: (px, cy, cz)
+      const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
+      if (gw >= n_waves)
+        return; // no barrier in this kernel
+      const int px = (int)(gw % sa.npx), cy = sa.lo[1] + (int)((gw / sa.npx) % sa.n[1]), cz = sa.lo[2] + (int)(gw / ((long long)sa.npx * sa.n[1]));
+      int       cl = lane / M;
+      const int sub = lane - cl * M;
+      int       cx  = sa.lo[0] + px * PPW + cl;
+      const bool active = cl < PPW && cx < sa.lo[0] + sa.n[0];
+      if (!active)
+        cx = sa.lo[0] + sa.n[0] - 1;
+      double *Tw = S_T + w * TB7;
+
+      const int o0 = f.origin_mul * cx + f.origin_add, o1 = f.origin_mul * cy + f.origin_add, o2 = f.origin_mul * cz + f.origin_add;
+      const long long ce = (cx + 1) + (long long)(g.nc[0] + 2) * ((cy + 1) + (long long)(g.nc[1] + 2) * (cz + 1));
+      const double *  ex = f.eig + (long long)f.inst[0][ce] * E, *ey = f.eig + (long long)f.inst[1][ce] * E,
+                   *ez = f.eig + (long long)f.inst[2][ce] * E;
+      // lanes along x, registers v[k*7 + j] (as in fdm_slice7_kernel)
+      const long long xoff = g.store_index_near(0, o0 + sub);
+      double          v[M2];
+#pragma unroll
+      for (int k = 0; k < M; ++k)
+        {
+          const double *plane = src + xoff + g.store_index_near(2, o2 + k) * g.stride[2];
+#pragma unroll
+          for (int jj = 0; jj < M; ++jj)
+            v[k * M + jj] = plane[g.store_index_near(1, o1 + jj) * g.stride[1]];
+        }
+      if (HAS_PRE)
+        {
+          const double wx = f.w_pre[0][(cx + 1) * M + sub];
+#pragma unroll
+          for (int k = 0; k < M; ++k)
+            {
+              const double wzx = f.w_pre[2][(cz + 1) * M + k] * wx;
+#pragma unroll
+              for (int jj = 0; jj < M; ++jj)
+                v[k * M + jj] *= f.w_pre[1][(cy + 1) * M + jj] * wzx;
+            }
+        }
+      double q[M2];
+      load_matrix7(q, ey);
+      sweep_fast7_reg<true>(v, q); // j -> b
+      load_matrix7(q, ez);
+      sweep_slow7_reg<true>(v, q); // k -> c
+      transpose7(v, Tw, lane, cl, sub); // layout B: lane = c, v[i*7 + b]
+      load_matrix7(q, ex);
+      sweep_slow7_reg<true>(v, q); // i -> a
+      {
+        const double lz = ez[M2 + sub];
+#pragma unroll
+        for (int b = 0; b < M; ++b)
+          {
+            const double lyz = ey[M2 + b] + lz;
+#pragma unroll
+            for (int a = 0; a < M; ++a)
+              {
+                // reciprocal with two Newton steps (full double precision)
+                const double sm = ex[M2 + a] + lyz;
+                double       r  = __builtin_amdgcn_rcp(sm);
+                r               = fma(fma(-sm, r, 1.0), r, r);
+                r               = fma(fma(-sm, r, 1.0), r, r);
+                v[a * M + b] *= r;
+              }
+          }
+      }
+      sweep_slow7_reg<false>(v, q);     // (the x matrix is still in q)
+      transpose7(v, Tw, lane, cl, sub); // layout A: lane = i, v[c*7 + b]
+      load_matrix7(q, ez);
+      sweep_slow7_reg<false>(v, q);
+      load_matrix7(q, ey);
+      sweep_fast7_reg<false>(v, q);
+      if (HAS_POST)
+        {
+          const double wx = f.w_post[0][(cx + 1) * M + sub];
+#pragma unroll
+          for (int k = 0; k < M; ++k)
+            {
+              const double wzx = f.w_post[2][(cz + 1) * M + k] * wx;
+#pragma unroll
+              for (int jj = 0; jj < M; ++jj)
+                v[k * M + jj] *= f.w_post[1][(cy + 1) * M + jj] * wzx;
+            }
+        }
+      if (active)
+        {
+          const long long cell = cx + (long long)g.nc[0] * (cy + (long long)g.nc[1] * cz);
+          double *        out  = tmp + cell * M3 + sub; // tmp[cell][k][j][i]
+#pragma unroll
+          for (int e = 0; e < M2; ++e)
+            out[e * M] = v[e];
+        }
+    }
   } // namespace
 
   bool
@@ -232,12 +387,25 @@ namespace asmamd
         sa.n[d]  = f.s7_hi[d] - f.s7_lo[d];
       }
     sa.npx = (sa.n[0] + PPW - 1) / PPW;
-    sa.qx  = f.eig + (long long)f.s7_inst[0] * E;
-    sa.qy  = f.eig + (long long)f.s7_inst[1] * E;
-    sa.qz  = f.eig + (long long)f.s7_inst[2] * E;
+    sa.qx  = f.eig + (long long)(f.s7_on == 1 ? f.s7_inst[0] : 0) * E;
+    sa.qy  = f.eig + (long long)(f.s7_on == 1 ? f.s7_inst[1] : 0) * E;
+    sa.qz  = f.eig + (long long)(f.s7_on == 1 ? f.s7_inst[2] : 0) * E;
     sa.inv = f.s7_inv;
     const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
     const unsigned  blocks  = (unsigned)((n_waves + WPB - 1) / WPB);
+    if (f.s7_on == 2)
+      {
+        // per-cell eigen-decompositions
+        if (f.has_pre && f.has_post)
+          hipLaunchKernelGGL((fdm_slice7_cell_kernel<true, true>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+        else if (f.has_pre)
+          hipLaunchKernelGGL((fdm_slice7_cell_kernel<true, false>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+        else if (f.has_post)
+          hipLaunchKernelGGL((fdm_slice7_cell_kernel<false, true>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+        else
+          hipLaunchKernelGGL((fdm_slice7_cell_kernel<false, false>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
+        return true;
+      }
     if (f.has_pre && f.has_post)
       hipLaunchKernelGGL((fdm_slice7_kernel<true, true>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
     else if (f.has_pre)

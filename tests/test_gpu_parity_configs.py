@@ -28,6 +28,9 @@ M7_CASES = [
     ((5, 4, 3), "dirichlet", "cartesian", 1, False),
     ((4, 3, 3), "periodic", "cartesian", 1, False),
     ((6, 3, 2), "dirichlet", "kershaw", 1, False),
+    # deformed meshes with cells all of whose patch DoFs exist: the per-cell-matrix slice-per-lane kernel takes those
+    ((12, 3, 3), "dirichlet", "kershaw", 2, True),
+    ((4, 4, 3), ["dirichlet", "neumann", "dirichlet"], "kershaw", 1, False),
 ]
 
 
