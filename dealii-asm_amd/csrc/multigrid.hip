@@ -87,8 +87,11 @@ namespace
     const long long n = (long long)a.out.size[0] * a.out.size[1] * a.out.size[2];
     for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
       {
-        int       c[3]  = {(int)(e % a.out.size[0]), (int)((e / a.out.size[0]) % a.out.size[1]),
-                    (int)(e / ((long long)a.out.size[0] * a.out.size[1]))};
+        // (32-bit index arithmetic: the boxes of a level have fewer than 2^31 entries, checked by the launcher; 64-bit
+        //  divisions cost several hundred instructions per entry)
+        const unsigned  eu = (unsigned)e, s0 = (unsigned)a.out.size[0], s01 = s0 * (unsigned)a.out.size[1];
+        const unsigned  ck = eu / s01, rem = eu - ck * s01, cj = rem / s0;
+        int             c[3] = {(int)(rem - cj * s0), (int)cj, (int)ck};
         const long long o  = box_offset(a.out, c[0], c[1], c[2]);
         const int       id = c[a.dir];
         const int       cnt = a.count[id];
@@ -101,6 +104,28 @@ namespace
           sum = fma(w[k], row[k * st], sum);
         out[o] = ADD ? out[o] + sum : sum;
       }
+  }
+
+  // the z direction: one grid row (blockIdx.y) per output plane, so that the plane's table entries (start, count,
+  // weights) are block-uniform and come through scalar loads, and the loop has a uniform trip count
+  template <bool ADD>
+  __global__ void __launch_bounds__(256)
+  transfer_pass_z_kernel(const PassArgs a, double *__restrict__ out, const double *__restrict__ in)
+  {
+    const unsigned e2 = blockIdx.x * 256u + threadIdx.x, s0 = (unsigned)a.out.size[0];
+    if (e2 >= s0 * (unsigned)a.out.size[1])
+      return;
+    const unsigned  cj = e2 / s0;
+    const int       ci = (int)(e2 - cj * s0), ck = (int)blockIdx.y;
+    const long long o  = box_offset(a.out, ci, (int)cj, ck);
+    const int       cnt = a.count[ck];
+    const double *  w   = a.val + (long long)ck * a.val_stride;
+    const double *  row = in + box_offset(a.in, ci, (int)cj, a.start[ck]);
+    const long long st  = a.in.stride[2];
+    double          sum = 0.;
+    for (int k = 0; k < cnt; ++k)
+      sum = fma(w[k], row[k * st], sum);
+    out[o] = ADD ? out[o] + sum : sum;
   }
 
   // dst_fine += P src_coarse: one thread per fine DoF
@@ -488,6 +513,12 @@ namespace
   launch_pass(asm_mg *mg, const PassArgs &a, double *out, const double *in)
   {
     const long long n = (long long)a.out.size[0] * a.out.size[1] * a.out.size[2];
+    if (a.dir == 2 && a.out.size[2] <= 65535)
+      {
+        const long long plane = (long long)a.out.size[0] * a.out.size[1];
+        hipLaunchKernelGGL((transfer_pass_z_kernel<ADD>), dim3((unsigned)((plane + 255) / 256), a.out.size[2]), dim3(256), 0, mg->stream, a, out, in);
+        return;
+      }
     hipLaunchKernelGGL((transfer_pass_kernel<ADD>), dim3(launch_blocks(n)), dim3(256), 0, mg->stream, a, out, in);
   }
 
@@ -1020,7 +1051,8 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
       lv.transfer.coarse = box_of(mg->levels[l - 1].layout);
       // larger levels: one pass per direction (ASM_MG_DIRECT_TRANSFER keeps the single-kernel form everywhere)
       const TransferArgs &t = lv.transfer;
-      if ((long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2] >= (1 << 17) && std::getenv("ASM_MG_DIRECT_TRANSFER") == nullptr)
+      if ((long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2] >= (1 << 17) &&
+          (long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2] < (1ll << 31) && std::getenv("ASM_MG_DIRECT_TRANSFER") == nullptr)
         {
           const size_t n_xy = (size_t)t.fine.size[0] * t.fine.size[1] * t.coarse.size[2], n_x = (size_t)t.fine.size[0] * t.coarse.size[1] * t.coarse.size[2];
           void *       q = nullptr;
