@@ -128,6 +128,27 @@ namespace
     out[o] = ADD ? out[o] + sum : sum;
   }
 
+  // the y direction in the same way: one grid row per output ROW index j, the threads of a block run over the (x, z) pairs
+  template <bool ADD>
+  __global__ void __launch_bounds__(256)
+  transfer_pass_y_kernel(const PassArgs a, double *__restrict__ out, const double *__restrict__ in)
+  {
+    const unsigned e2 = blockIdx.x * 256u + threadIdx.x, s0 = (unsigned)a.out.size[0];
+    if (e2 >= s0 * (unsigned)a.out.size[2])
+      return;
+    const unsigned  ck = e2 / s0;
+    const int       ci = (int)(e2 - ck * s0), cj = (int)blockIdx.y;
+    const long long o  = box_offset(a.out, ci, cj, (int)ck);
+    const int       cnt = a.count[cj];
+    const double *  w   = a.val + (long long)cj * a.val_stride;
+    const double *  row = in + box_offset(a.in, ci, a.start[cj], (int)ck);
+    const long long st  = a.in.stride[1];
+    double          sum = 0.;
+    for (int k = 0; k < cnt; ++k)
+      sum = fma(w[k], row[k * st], sum);
+    out[o] = ADD ? out[o] + sum : sum;
+  }
+
   // dst_fine += P src_coarse: one thread per fine DoF
   __global__ void __launch_bounds__(256)
   prolongate_add_kernel(const TransferArgs t, double *__restrict__ dst, const double *__restrict__ src)
@@ -517,6 +538,12 @@ namespace
       {
         const long long plane = (long long)a.out.size[0] * a.out.size[1];
         hipLaunchKernelGGL((transfer_pass_z_kernel<ADD>), dim3((unsigned)((plane + 255) / 256), a.out.size[2]), dim3(256), 0, mg->stream, a, out, in);
+        return;
+      }
+    if (a.dir == 1 && a.out.size[1] <= 65535)
+      {
+        const long long xz = (long long)a.out.size[0] * a.out.size[2];
+        hipLaunchKernelGGL((transfer_pass_y_kernel<ADD>), dim3((unsigned)((xz + 255) / 256), a.out.size[1]), dim3(256), 0, mg->stream, a, out, in);
         return;
       }
     hipLaunchKernelGGL((transfer_pass_kernel<ADD>), dim3(launch_blocks(n)), dim3(256), 0, mg->stream, a, out, in);
