@@ -124,6 +124,7 @@ class AsmSolverParams(C.Structure):
         ("rel_tolerance", C.c_double),
         ("right_preconditioning", C.c_int32),
         ("max_n_tmp_vectors", C.c_int32),
+        ("keep_preconditioned_basis", C.c_int32),
     ]
 
 
@@ -503,7 +504,7 @@ class Context:
         self._check(self.lib.asm_vec_constraints_set_zero(self.handle, y.ptr))
 
     def solve(self, x, b, solver="GMRES", preconditioner="Chebyshev", mg=None, rel_tol=1e-2, abs_tol=1e-10, max_iter=1000,
-              right_preconditioning=True, max_n_tmp_vectors=30):
+              right_preconditioning=True, max_n_tmp_vectors=30, keep_preconditioned_basis=False):
         """solve() of element_centered_preconditioners_01.cc:108-263 (x = 0 initially); returns AsmSolverResult"""
         sp = AsmSolverParams()
         self.lib.asm_solver_params_default(C.byref(sp))
@@ -511,6 +512,7 @@ class Context:
         sp.rel_tolerance, sp.abs_tolerance, sp.max_iterations = rel_tol, abs_tol, max_iter
         sp.right_preconditioning = 1 if right_preconditioning else 0
         sp.max_n_tmp_vectors = max_n_tmp_vectors
+        sp.keep_preconditioned_basis = 1 if keep_preconditioned_basis else 0
         res = AsmSolverResult()
         err = self.lib.asm_solve(self.handle, mg.handle if mg is not None else None, SYSTEM_PRECONDITIONER[preconditioner],
                                  C.byref(sp), x.ptr, b.ptr, C.byref(res))

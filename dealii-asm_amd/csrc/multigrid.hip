@@ -715,6 +715,8 @@ namespace
     if (res.converged)
       return ASM_OK;
     std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 1), hneg(m + 1);
+    std::vector<double *> Z;
+    bool                  keep_z = right && sp.keep_preconditioned_basis != 0;
     int                 it = 0;
     while (it < sp.max_iterations)
       {
@@ -728,8 +730,25 @@ namespace
             // w = A M^-1 v_k (right) or M^-1 A v_k (left), into V[k+1]
             if (right)
               {
-                KS_TRY(apply_preconditioner(pc, error, t, V[k]));
-                KS_CTX(asm_op_vmult(ctx, V[k + 1], t));
+                // asm_solver_params::keep_preconditioned_basis: the preconditioned basis vectors are kept (as flexible
+                // GMRES does): x += sum_i y_i M^-1 v_i then needs no further application of the preconditioner at the end
+                // of the cycle - one V-cycle less per solve.  Default, and without the memory: the vector t is reused and
+                // the preconditioner applied to the combination, as deal.II's SolverGMRES does.
+                double *zk = t;
+                if (keep_z)
+                  {
+                    if ((int)Z.size() <= k)
+                      Z.push_back(w.get());
+                    if (Z[k] == nullptr)
+                      {
+                        keep_z = false;
+                        Z.pop_back();
+                      }
+                    else
+                      zk = Z[k];
+                  }
+                KS_TRY(apply_preconditioner(pc, error, zk, V[k]));
+                KS_CTX(asm_op_vmult(ctx, V[k + 1], zk));
               }
             else
               {
@@ -778,18 +797,26 @@ namespace
               s -= H[(size_t)i * m + j] * y[j];
             y[i] = s / H[(size_t)i * m + i];
           }
-        KS_CTX(asm_vec_zero(ctx, u));
-        {
-          double unused = 0.;
-          KS_CTX(asm_vec_multi_axpy_norm(ctx, u, V.data(), y.data(), k_done, &unused));
-        }
-        if (right)
+        if (right && keep_z && (int)Z.size() >= k_done)
           {
-            KS_TRY(apply_preconditioner(pc, error, t, u));
-            KS_CTX(asm_vec_axpby(ctx, x, 1., t, 1.));
+            double unused = 0.;
+            KS_CTX(asm_vec_multi_axpy_norm(ctx, x, Z.data(), y.data(), k_done, &unused)); // x += sum_i y_i M^-1 v_i
           }
         else
-          KS_CTX(asm_vec_axpby(ctx, x, 1., u, 1.));
+          {
+            KS_CTX(asm_vec_zero(ctx, u));
+            {
+              double unused = 0.;
+              KS_CTX(asm_vec_multi_axpy_norm(ctx, u, V.data(), y.data(), k_done, &unused));
+            }
+            if (right)
+              {
+                KS_TRY(apply_preconditioner(pc, error, t, u));
+                KS_CTX(asm_vec_axpby(ctx, x, 1., t, 1.));
+              }
+            else
+              KS_CTX(asm_vec_axpby(ctx, x, 1., u, 1.));
+          }
         if (res.final_residual <= tol)
           {
             res.converged = 1;
@@ -961,6 +988,7 @@ asm_solver_params_default(asm_solver_params *p)
   p->rel_tolerance         = 1e-2;
   p->right_preconditioning = 1;
   p->max_n_tmp_vectors     = 30;
+  p->keep_preconditioned_basis = 0;
 }
 
 const char *

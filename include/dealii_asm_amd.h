@@ -427,6 +427,10 @@ typedef struct asm_solver_params
   double  rel_tolerance;         /* "rel tolerance", 1e-2 */
   int32_t right_preconditioning; /* "use right preconditioning", true */
   int32_t max_n_tmp_vectors;     /* "max n tmp vectors", 30 (Krylov vectors per restart = this - 2) */
+  /* GMRES with right preconditioning: 0 (default) = deal.II's SolverGMRES, which applies the preconditioner once more to the
+   * combination of the basis at the end of a cycle; 1 = keep the preconditioned basis vectors M^-1 v_i (as SolverFGMRES does):
+   * one preconditioner application less per cycle for as many more work vectors; the same iterates for a linear preconditioner */
+  int32_t keep_preconditioned_basis;
 } asm_solver_params;
 typedef struct asm_solver_result
 {

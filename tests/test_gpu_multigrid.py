@@ -238,6 +238,12 @@ def test_direct_coarse_solver(pkg, nc, p, bc, geometry, mg_type, solver, weighti
         assert rel(xv.get(), x_ref) < 1e-7
         true_res = np.linalg.norm(b - op.vmult(xv.get(), unit_constrained=True))
         assert true_res <= 1.01e-8 * np.linalg.norm(b)  # linear preconditioner: the GMRES estimate is the true residual
+        if solver == "GMRES":
+            # keeping the preconditioned basis (one V-cycle less per cycle) gives the same iterates for a linear preconditioner
+            x1 = xv.get()
+            res2 = mg.fine.solve(xv, bv, solver=solver, preconditioner="Multigrid", mg=mg, rel_tol=1e-8, abs_tol=0.0,
+                                 keep_preconditioned_basis=True)
+            assert res2.n_iterations == res.n_iterations and rel(xv.get(), x1) < 1e-10
         bv.free()
         xv.free()
 

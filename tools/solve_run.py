@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--tmp-vectors", type=int, default=17)
     ap.add_argument("--best-of", type=int, default=5)
     ap.add_argument("--coarse", default="cg", choices=["cg", "smoother", "direct"])
+    ap.add_argument("--keep-basis", action="store_true", help="GMRES keeps the preconditioned basis (asm_solver_params::keep_preconditioned_basis)")
     args = ap.parse_args()
     pkg = load_package()
     prm = pkg.make_params(degree=4, n_cells=args.cells, boundary="dirichlet", geometry=args.geometry, kershaw_eps=(0.3, 0.3),
@@ -49,7 +50,7 @@ def main():
         fine.synchronize()
         t0 = time.perf_counter()
         res = fine.solve(x, b, solver=args.solver, preconditioner="Multigrid", mg=mg, rel_tol=args.rel_tol, abs_tol=1e-10,
-                         max_n_tmp_vectors=args.tmp_vectors)
+                         max_n_tmp_vectors=args.tmp_vectors, keep_preconditioned_basis=args.keep_basis)
         fine.synchronize()
         if i > 0:
             best = min(best, time.perf_counter() - t0)
@@ -65,7 +66,7 @@ def main():
     t_v = (time.perf_counter() - t0) / 5
     levels = [(c.n_dofs) for c in mg.levels]
     print(f"cells {args.cells} {args.geometry} n_dofs {fine.n_dofs} levels {levels} {args.solver} k={args.degree} {args.weighting} "
-          f"n_overlap={args.n_overlap} patch={args.patch} coarse={args.coarse}: it {res.n_iterations} converged {res.converged} "
+          f"n_overlap={args.n_overlap} patch={args.patch} coarse={args.coarse}{' keep-basis' if args.keep_basis else ''}: it {res.n_iterations} converged {res.converged} "
           f"time {best:.4e} s  (V-cycle {t_v * 1e3:.3f} ms, setup {t_setup:.2f} s)")
 
 
