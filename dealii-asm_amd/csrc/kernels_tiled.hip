@@ -895,8 +895,9 @@ namespace asmamd
       // stored there, where the wave would otherwise only wait - the eight waves of the workgroup then do not all enter
       // the vector-memory path together right after the barrier (profiles/r02_tiled_phase_stamps.txt).
       // Measured: the Laplace sweeps gain 6-9 %, the FDM sweeps (whose second update operand is requested late and
-      // would have to be waited for before the barrier) lose 2-13 %: split for the Laplace modes only.
-      constexpr bool split = (MODE == OP_PLAIN || MODE == OP_RESIDUAL);
+      // would have to be waited for before the barrier) lose 2-13 % in the modes with update operands.
+      // (the FDM modes without update operands gain as well: -1 % Dirichlet, -4.5 % periodic box)
+      constexpr bool split = (MODE == OP_PLAIN || MODE == OP_RESIDUAL || MODE == PC_PLAIN || MODE == PC_FIRST);
       const bool     late  = !split || (c.below_ok && c.sub == 0);
 #if !(defined(ASM_ABLATE) && (ASM_ABLATE & 8))
       // ---- y: row 4 -> row 0 of the cell above
@@ -913,7 +914,8 @@ namespace asmamd
       if (split)
         {
           // the update operands (and the next layer's staged rows, requested long ago) have arrived
-          gather_wait();
+          if (na)
+            gather_wait();
           if (c.own_row && !late)
             store_rows();
         }
