@@ -68,6 +68,7 @@ struct asm_ctx
   int                      device = 0; // HIP device ordinal every call of this context runs on
   int                      n_cu   = 0; // its compute units (tile scheduling of the tiled sweeps)
   int                      laplace_rows = 0; // TiledArgs::rows of the tiled Laplace sweep (tune_tiled_laplace)
+  const int *              order_a = nullptr, *order_p = nullptr; // work order of the single-phase tiled sweeps (tiled_order): A, P
   DevGrid                  g;
   DevFdm                   f;
   DevOp                    op;
@@ -536,6 +537,7 @@ namespace
     a.device = ctx->device;
     a.n_cu   = ctx->n_cu;
     a.rows   = ctx->laplace_rows;
+    a.order  = (a.mode == OP_PLAIN || a.mode == OP_RESIDUAL) ? ctx->order_a : ctx->order_p;
     if (!ov && ctx->debug_two_phase)
       {
         a.phase = 1;
@@ -1447,6 +1449,25 @@ asm_create(const asm_params *p, asm_ctx **out)
     }
   if ((err = tune_tiled_laplace(ctx)))
     return fail(err);
+  // single-phase tiled sweeps: the workgroups at Dirichlet faces first (kernels.h: tiled_order); ASM_NO_TILED_ORDER keeps
+  // the launch positions (experiments)
+  if ((ctx->s.laplace_tiled || ctx->s.fdm_tiled) && std::getenv("ASM_NO_TILED_ORDER") == nullptr)
+    {
+      std::vector<int> order;
+      if (ctx->s.fdm_tiled || ctx->laplace_rows == 0)
+        {
+          tiled_order(ctx->g, ctx->n_cu, 0, order);
+          if ((err = upload(ctx, order, &ctx->order_p)))
+            return fail(err);
+        }
+      ctx->order_a = ctx->order_p;
+      if (ctx->s.laplace_tiled && ctx->laplace_rows != 0)
+        {
+          tiled_order(ctx->g, ctx->n_cu, ctx->laplace_rows, order);
+          if ((err = upload(ctx, order, &ctx->order_a)))
+            return fail(err);
+        }
+    }
   if (hipStreamSynchronize(ctx->stream) != hipSuccess)
     {
       ctx->error = "device error during setup";

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace asmamd
 {
   // ---- generic sweeps (kernels_generic.hip): dst must be zeroed by the caller,
@@ -65,7 +67,15 @@ namespace asmamd
     int n_cu   = 0;
     // Laplace sweep: cell rows (waves) per workgroup of the second-generation kernel (9, 10, 11), 0 = first generation
     int rows = 0;
+    // single-phase launches: work index of every launch position (tiled_order), or nullptr = the positions themselves
+    const int *order = nullptr;
   };
+  // Work order of a single-phase tiled sweep (device-independent, host side).  The workgroups at Dirichlet faces live
+  // up to 1.5 times as long as the others (constrained rows, full-matrix sweeps; profiles/r03_workgroup_trace.txt), and a
+  // launch of three rounds of workgroups ended 11-12 % after the average compute unit had finished.  order[p] = work
+  // index (tile x fastest, then tile y, then z chunk) taken by launch position p, where every XCD keeps its contiguous range of
+  // work indices (L2 locality) but takes the expensive ones first.  Returns the number of positions (0: nothing to reorder).
+  int tiled_order(const DevGrid &g, int n_cu, int rows, std::vector<int> &order);
   bool laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st);
   bool fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st);
 

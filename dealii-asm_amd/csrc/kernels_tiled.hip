@@ -77,6 +77,30 @@ namespace asmamd
 #ifdef ASM_STAMP
     // diagnostic build: cycles (s_memtime) an interior wave spends between the STAMP marks
     __device__ unsigned long long g_stamps[32];
+    // ... and the life of every workgroup: {start, end (s_memrealtime, 100 MHz), XCC id << 32 | hardware id, kernel tag << 32 | block}
+    __device__ unsigned long long g_wgtrace[16384][4];
+    __device__ unsigned int       g_wgtrace_n;
+#  define WGTRACE_BEGIN(tag)                                                                   \
+    const unsigned long long wgt_t0 = __builtin_amdgcn_s_memrealtime();                       \
+    constexpr unsigned       wgt_tag = tag;
+#  define WGTRACE_END()                                                                        \
+    do                                                                                        \
+      {                                                                                       \
+        __syncthreads();                                                                      \
+        if (threadIdx.x == 0)                                                                 \
+          {                                                                                   \
+            const unsigned slot = atomicAdd(&g_wgtrace_n, 1u);                                \
+            if (slot < 16384)                                                                 \
+              {                                                                               \
+                g_wgtrace[slot][0] = wgt_t0;                                                  \
+                g_wgtrace[slot][1] = __builtin_amdgcn_s_memrealtime();                        \
+                g_wgtrace[slot][2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | \
+                                     (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+                g_wgtrace[slot][3] = ((unsigned long long)wgt_tag << 32) | blockIdx.x;        \
+              }                                                                               \
+          }                                                                                   \
+      }                                                                                       \
+    while (0)
     struct StampCtx
     {
       bool               on;
@@ -84,7 +108,7 @@ namespace asmamd
     };
 #  define STAMP_DECL(base)                                                                  \
     StampCtx stamp_ctx;                                                                     \
-    stamp_ctx.on = (blockIdx.x == gridDim.x / 2 + 3) && ((threadIdx.x >> 6) == 3);          \
+    stamp_ctx.on = (tx == tl.ntx / 2 && ty == tl.nty / 2 && zc == tl.nzc / 2) && ((threadIdx.x >> 6) == 3); /* an interior tile */ \
     stamp_ctx.t  = __builtin_amdgcn_s_memtime();                                            \
     for (int i = 0; i < 16; ++i)                                                            \
       stamp_ctx.acc[i] = 0;                                                                 \
@@ -116,6 +140,8 @@ namespace asmamd
 #  define STAMP_DECL(base)
 #  define STAMP(i)
 #  define STAMP_WAIT_VM()
+#  define WGTRACE_BEGIN(tag)
+#  define WGTRACE_END()
 #  define STAMP_FLUSH()
 #  define STAMP_PARAM
 #  define STAMP_ARG
@@ -149,9 +175,11 @@ namespace asmamd
     __device__ __forceinline__ void
     workgroup_of_block(const TiledArgs &a, const Tiling &tl, int &tx, int &ty, int &zc)
     {
-      const int i = xcd_remap(blockIdx.x, gridDim.x);
+      int i = xcd_remap(blockIdx.x, gridDim.x);
       if (a.phase == 0)
         {
+          if (a.order != nullptr) // expensive workgroups first (tiled_order); a scalar load
+            i = ((const __attribute__((address_space(4))) int *)a.order)[i];
           tx = i % tl.ntx;
           ty = (i / tl.ntx) % tl.nty;
           zc = i / (tl.ntx * tl.nty);
@@ -993,6 +1021,7 @@ namespace asmamd
     __global__ void __launch_bounds__(NT, TY >= 8 ? TY / 4 : 2)
     fdm_tiled_kernel(const DevGrid g, const DevFdm f, const TiledArgs a, const Tiling tl)
     {
+      WGTRACE_BEGIN(1)
       extern __shared__ __attribute__((aligned(16))) double lds[];
       double *S_T   = lds;
       double *S_Y   = S_T + LDS_T;
@@ -1271,6 +1300,7 @@ namespace asmamd
             v[i] = carry[i];
           merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), v, P * g.nc[2], ops STAMP_ARG);
         }
+      WGTRACE_END();
     }
 
     // ---------------------------------------------------------------------------
@@ -1288,6 +1318,7 @@ namespace asmamd
     __global__ void __launch_bounds__(NT, TY >= 8 ? TY / 4 : 2)
     laplace_cart_tiled_kernel(const DevGrid g, const DevOp op, const TiledArgs a, const Tiling tl)
     {
+      WGTRACE_BEGIN(0)
       extern __shared__ __attribute__((aligned(16))) double lds[];
       double *S_T = lds;
       double *S_Y = S_T + LDS_T;
@@ -1391,6 +1422,7 @@ namespace asmamd
             u[i] = carry[i];
           merge_y_and_store<MODE, 1>(g, lp, c, a, S_Y + par * (LDS_Y / 2), u, P * g.nc[2], ops STAMP_ARG);
         }
+      WGTRACE_END();
     }
 
 
@@ -1615,6 +1647,12 @@ namespace asmamd
       return a.phase == 0 ? total : (a.phase == 1 ? tl.n_first : total - tl.n_first);
     }
 
+    int
+    tile_rows_of(const int rows)
+    {
+      return rows >= 9 && rows <= 11 ? rows - 1 : OY;
+    }
+
     // The kernels need more dynamic LDS than the default limit: raise it once per kernel and device
     // (bit d of `done` = device d).  false: the attribute was refused, the launch would be rejected.
     template <typename K>
@@ -1633,6 +1671,45 @@ namespace asmamd
       return true;
     }
   } // namespace
+
+  int
+  tiled_order(const DevGrid &g, const int n_cu, const int rows, std::vector<int> &order)
+  {
+    order.clear();
+    if (g.p != P)
+      return 0;
+    TiledArgs a{};
+    a.phase      = 0;
+    a.n_cu       = n_cu;
+    const Tiling tl = make_tiling(g, a, tile_rows_of(rows));
+    const int    n  = tl.ntx * tl.nty * tl.nzc;
+    // cost class of a workgroup: the number of Dirichlet faces its cells touch
+    const auto faces = [&](const int i) {
+      const int tx = i % tl.ntx, ty = (i / tl.ntx) % tl.nty, zc = i / (tl.ntx * tl.nty);
+      const int t[3] = {tx, ty, zc}, nt[3] = {tl.ntx, tl.nty, tl.nzc};
+      int       c    = 0;
+      for (int d = 0; d < 3; ++d)
+        c += (g.dir_lo[d] && t[d] == 0 ? 1 : 0) + (g.dir_hi[d] && t[d] == nt[d] - 1 ? 1 : 0);
+      return c;
+    };
+    bool any = false;
+    for (int i = 0; i < n && !any; ++i)
+      any = faces(i) != 0;
+    if (!any || n < 16)
+      return 0;
+    order.resize(n);
+    // the contiguous range of every XCD (xcd_remap), expensive workgroups first, otherwise in place
+    for (int x = 0; x < 8; ++x)
+      {
+        const int begin = x * (n >> 3) + std::min(x, n & 7), size = (n >> 3) + (x < (n & 7) ? 1 : 0);
+        int       o     = begin;
+        for (int cls = 6; cls >= 0; --cls)
+          for (int i = begin; i < begin + size; ++i)
+            if (faces(i) == cls)
+              order[o++] = i;
+      }
+    return n;
+  }
 
   template <int MODE>
   static bool
@@ -1744,6 +1821,26 @@ namespace asmamd
     return dispatch_fdm_mode<false, false>(g, f, a, tl, st);
   }
 #ifdef ASM_STAMP
+  // workgroup trace of the diagnostic builds (tools/wgtrace_run.py); not part of the C ABI
+  extern "C" int
+  asm_debug_wgtrace(unsigned long long *out, int max_rows, int reset)
+  {
+    (void)hipDeviceSynchronize();
+    unsigned n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgtrace_n), sizeof(n));
+    if (n > 16384u)
+      n = 16384u;
+    if ((int)n > max_rows)
+      n = (unsigned)max_rows;
+    if (n > 0 && out != nullptr)
+      (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgtrace), (size_t)n * 4 * sizeof(unsigned long long));
+    if (reset)
+      {
+        const unsigned z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgtrace_n), &z, sizeof(z));
+      }
+    return (int)n;
+  }
   void
   tiled_debug_stamps(unsigned long long out[32], bool reset)
   {
