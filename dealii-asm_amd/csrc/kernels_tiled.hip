@@ -1683,30 +1683,30 @@ namespace asmamd
     a.n_cu       = n_cu;
     const Tiling tl = make_tiling(g, a, tile_rows_of(rows));
     const int    n  = tl.ntx * tl.nty * tl.nzc;
-    // cost class of a workgroup: the number of Dirichlet faces its cells touch
-    const auto faces = [&](const int i) {
+    // extra life of a workgroup whose cells touch a Dirichlet face, in per cent of an interior one's (measured:
+    // profiles/r03_workgroup_trace.txt; the low y face costs most: every DoF row of a lane is constrained there)
+    static const int extra[3][2] = {{20, 13}, {33, 10}, {0, 6}};
+    const auto cost = [&](const int i) {
       const int tx = i % tl.ntx, ty = (i / tl.ntx) % tl.nty, zc = i / (tl.ntx * tl.nty);
       const int t[3] = {tx, ty, zc}, nt[3] = {tl.ntx, tl.nty, tl.nzc};
       int       c    = 0;
       for (int d = 0; d < 3; ++d)
-        c += (g.dir_lo[d] && t[d] == 0 ? 1 : 0) + (g.dir_hi[d] && t[d] == nt[d] - 1 ? 1 : 0);
+        c += (g.dir_lo[d] && t[d] == 0 ? extra[d][0] : 0) + (g.dir_hi[d] && t[d] == nt[d] - 1 ? extra[d][1] : 0);
       return c;
     };
     bool any = false;
     for (int i = 0; i < n && !any; ++i)
-      any = faces(i) != 0;
+      any = cost(i) != 0;
     if (!any || n < 16)
       return 0;
     order.resize(n);
-    // the contiguous range of every XCD (xcd_remap), expensive workgroups first, otherwise in place
+    // the contiguous range of every XCD (xcd_remap), expensive workgroups first, equally expensive ones in place
     for (int x = 0; x < 8; ++x)
       {
         const int begin = x * (n >> 3) + std::min(x, n & 7), size = (n >> 3) + (x < (n & 7) ? 1 : 0);
-        int       o     = begin;
-        for (int cls = 6; cls >= 0; --cls)
-          for (int i = begin; i < begin + size; ++i)
-            if (faces(i) == cls)
-              order[o++] = i;
+        for (int i = 0; i < size; ++i)
+          order[begin + i] = begin + i;
+        std::stable_sort(order.begin() + begin, order.begin() + begin + size, [&](const int u, const int v) { return cost(u) > cost(v); });
       }
     return n;
   }

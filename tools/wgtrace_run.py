@@ -54,3 +54,21 @@ for tag, name in ((0, "Laplace"), (1, "FDM")):
         print(f"  gap between consecutive workgroups on a CU: mean {gaps.mean():.2f} median {np.median(gaps):.2f} max {gaps.max():.2f} us (n={len(gaps)})")
     h, edges = np.histogram(dur, bins=8)
     print("  life histogram (us):", ", ".join(f"{edges[i]:.0f}-{edges[i+1]:.0f}: {h[i]}" for i in range(len(h))))
+    # life by cost class (needs ASM_NO_TILED_ORDER=1: launch position = work index)
+    if os.environ.get("ASM_NO_TILED_ORDER"):
+        nb = len(sel)
+        b = (sel[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        xcd, idx = b & 7, b >> 3
+        i = xcd * (nb >> 3) + np.minimum(xcd, nb & 7) + idx
+        ntx, nty = (cells[0] + 10) // 11, (cells[1] + 6) // 7
+        nzc = nb // (ntx * nty)
+        tx, ty, zc = i % ntx, (i // ntx) % nty, i // (ntx * nty)
+        for name2, m in (("interior", (tx > 0) & (tx < ntx - 1) & (ty > 0) & (ty < nty - 1) & (zc > 0) & (zc < nzc - 1)),
+                         ("x low only", (tx == 0) & (ty > 0) & (ty < nty - 1) & (zc > 0) & (zc < nzc - 1)),
+                         ("x high only", (tx == ntx - 1) & (ty > 0) & (ty < nty - 1) & (zc > 0) & (zc < nzc - 1)),
+                         ("y low only", (ty == 0) & (tx > 0) & (tx < ntx - 1) & (zc > 0) & (zc < nzc - 1)),
+                         ("y high only", (ty == nty - 1) & (tx > 0) & (tx < ntx - 1) & (zc > 0) & (zc < nzc - 1)),
+                         ("z low only", (zc == 0) & (tx > 0) & (tx < ntx - 1) & (ty > 0) & (ty < nty - 1)),
+                         ("z high only", (zc == nzc - 1) & (tx > 0) & (tx < ntx - 1) & (ty > 0) & (ty < nty - 1))):
+            if m.any():
+                print(f"  class {name2:12s}: n={m.sum():4d} life mean {dur[m].mean():.1f} us (min {dur[m].min():.1f}, max {dur[m].max():.1f})")
