@@ -113,6 +113,12 @@ class AsmMgParams(C.Structure):
         ("coarse_rel_tolerance", C.c_double),
         ("coarse_max_iterations", C.c_int32),
         ("estimate_eigenvalues", C.c_int32),
+        ("n_coarse_cycles", C.c_int32),
+        ("intermediate_smoother", C.c_int32),
+        ("intermediate_precond_type", C.c_int32),
+        ("intermediate_cheb_degree", C.c_int32),
+        ("keep_duplicate_level", C.c_int32),
+        ("struct_size", C.c_uint32),
     ]
 
 
@@ -196,6 +202,7 @@ EXPORTED_SYMBOLS = [
     "asm_mg_prolongate_add",
     "asm_mg_restrict",
     "asm_mg_vmult",
+    "asm_mg_coarse_failures",
     "asm_solver_params_default",
     "asm_solve",
 ]
@@ -644,10 +651,19 @@ class Multigrid:
     """Level hierarchy + V-cycle (PreconditionerGMG, include/multigrid.h:40-520) over contexts of this library."""
 
     def __init__(self, fine_params: AsmParams, mg_type="h", p_sequence="bisect", one_sided=False, coarse="cg",
-                 coarse_rel_tol=1e-3, coarse_max_iter=200, estimate_eigenvalues=True):
+                 coarse_rel_tol=1e-3, coarse_max_iter=200, estimate_eigenvalues=True, n_coarse_cycles=1,
+                 intermediate_smoother=None, keep_duplicate_level=True):
+        """intermediate_smoother: None ("mg intermediate smoother" without a type = the mg smoother) or
+        (inner preconditioner "FDM" | "Diagonal", Chebyshev degree)"""
         self.lib = load_library()
         mp = AsmMgParams()
         self.lib.asm_mg_params_default(C.byref(mp))
+        mp.n_coarse_cycles = n_coarse_cycles
+        mp.keep_duplicate_level = 1 if keep_duplicate_level else 0
+        if intermediate_smoother is not None:
+            mp.intermediate_smoother = 1
+            mp.intermediate_precond_type = PRECOND[intermediate_smoother[0]]
+            mp.intermediate_cheb_degree = int(intermediate_smoother[1])
         mp.mg_type, mp.p_sequence = MG_TYPE[mg_type], MG_P_SEQUENCE[p_sequence]
         mp.one_sided_v_cycle = 1 if one_sided else 0
         mp.coarse_solver = MG_COARSE[coarse]

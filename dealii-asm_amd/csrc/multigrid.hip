@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -264,6 +265,10 @@ struct asm_mg
   // ASM_MG_COARSE_DIRECT: dense inverse of the level-0 operator, [n][n] over the owned DoFs
   double *    coarse_inverse = nullptr;
   int         coarse_n       = 0;
+  // the last level of degree 1 (element_centered_preconditioners_01.cc:677-685): top of the intermediate multigrid
+  int         intermediate_level = 0;
+  double *    rc_r = nullptr, *rc_d = nullptr; // "n coarse cycles" > 1: residual and correction on that level
+  long long   coarse_not_converged = 0;        // coarse CG solves that hit their iteration limit
   std::string error;
 };
 
@@ -340,7 +345,8 @@ namespace
     bool operator==(const LevelSpec &o) const { return nc[0] == o.nc[0] && nc[1] == o.nc[1] && nc[2] == o.nc[2] && p == o.p; }
   };
 
-  // element_centered_preconditioners_01.cc:640-672; a level the 'ph' / 'hp' lists name twice is kept once
+  // element_centered_preconditioners_01.cc:640-672.  The 'ph' / 'hp' lists name the joint level twice; both copies are
+  // levels (identity transfer, a smoother each) unless mp.keep_duplicate_level == 0
   std::vector<LevelSpec>
   level_sequence(const asm_params &fine, const asm_mg_params &mp)
   {
@@ -353,7 +359,7 @@ namespace
     std::vector<LevelSpec> lv;
     const auto             add = [&](const std::array<int, 3> &m, const int p) {
       const LevelSpec s{{m[0], m[1], m[2]}, p};
-      if (lv.empty() || !(lv.back() == s))
+      if (mp.keep_duplicate_level != 0 || lv.empty() || !(lv.back() == s))
         lv.push_back(s);
     };
     switch (mp.mg_type)
@@ -921,13 +927,27 @@ namespace
     return ASM_OK;
   }
 
+  // `top`: the level is entered as a level of the multigrid above, i.e. - on the intermediate level - as the coarse-grid
+  // problem of the upper multigrid: "n coarse cycles" Richardson steps preconditioned by the lower one
+  // (SolverRelaxation under IterationNumberControl, include/multigrid.h:346-365)
   int
-  v_cycle(asm_mg *mg, const int level, double *x = nullptr, double *b = nullptr)
+  v_cycle(asm_mg *mg, const int level, double *x = nullptr, double *b = nullptr, const bool top = true)
   {
     Level &lv = mg->levels[level];
     // (the finest level works on the caller's vectors)
     x = x ? x : lv.x;
     b = b ? b : lv.b;
+    if (top && level == mg->intermediate_level && mg->mp.n_coarse_cycles > 1 && level + 1 < (int)mg->levels.size())
+      {
+        MG_TRY(v_cycle(mg, level, x, b, false)); // x = M b (from x = 0)
+        for (int c = 1; c < mg->mp.n_coarse_cycles; ++c)
+          {
+            MG_CTX(mg, lv.ctx, asm_op_vmult_fused(lv.ctx, ASM_FUSED_RESIDUAL, mg->rc_r, x, b)); // r = b - A x
+            MG_TRY(v_cycle(mg, level, mg->rc_d, mg->rc_r, false));
+            MG_CTX(mg, lv.ctx, asm_vec_axpby(lv.ctx, x, 1.0, mg->rc_d, 1.0));                  // x += M r
+          }
+        return ASM_OK;
+      }
     if (level == 0)
       {
         if (mg->mp.coarse_solver == ASM_MG_COARSE_SMOOTHER)
@@ -950,7 +970,10 @@ namespace
         sp.max_iterations = mg->mp.coarse_max_iterations;
         asm_solver_result res;
         double *const     work[4] = {lv.r, mg->cg_z, mg->cg_p, mg->cg_q};
-        return solve_cg(lv.ctx, Preconditioner{ASM_SP_INNER, lv.ctx, nullptr}, sp, x, b, res, mg->error, work);
+        const int         err     = solve_cg(lv.ctx, Preconditioner{ASM_SP_INNER, lv.ctx, nullptr}, sp, x, b, res, mg->error, work);
+        if (err == ASM_OK && !res.converged)
+          ++mg->coarse_not_converged; // (asm_mg_coarse_failures: the V-cycle went on with an inexact coarse correction)
+        return err;
       }
     Level &lc = mg->levels[level - 1];
     MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, x, b));                                    // pre-smoothing, x_0 = 0
@@ -977,6 +1000,12 @@ asm_mg_params_default(asm_mg_params *p)
   p->coarse_rel_tolerance  = 1e-3;
   p->coarse_max_iterations = 200;
   p->estimate_eigenvalues  = 1;
+  p->n_coarse_cycles       = 1; // "n coarse cycles" (include/precondition.h:127)
+  p->intermediate_smoother = 0; // "mg intermediate smoother" without a type: the mg smoother (precondition.h:148-158)
+  p->intermediate_precond_type = ASM_PRECOND_DIAGONAL;
+  p->intermediate_cheb_degree  = 3;
+  p->keep_duplicate_level  = 1;
+  p->struct_size           = (uint32_t)sizeof(asm_mg_params);
 }
 
 void
@@ -1008,6 +1037,10 @@ asm_mg_destroy(asm_mg *mg)
     for (double *v : {mg->cg_p, mg->cg_z, mg->cg_q})
       if (v)
         (void)asm_vector_free(mg->levels[0].ctx, v);
+  if ((int)mg->levels.size() > mg->intermediate_level && mg->levels[mg->intermediate_level].ctx)
+    for (double *v : {mg->rc_r, mg->rc_d})
+      if (v)
+        (void)asm_vector_free(mg->levels[mg->intermediate_level].ctx, v);
   if (mg->coarse_inverse)
     (void)hipFree(mg->coarse_inverse);
   for (Level &lv : mg->levels)
@@ -1049,10 +1082,28 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
       g_mg_create_error = "Multigrid variant / p sequence is not known!";
       return ASM_ERR_INVALID_VALUE;
     }
+  if (mp.struct_size != (uint32_t)sizeof(asm_mg_params))
+    {
+      g_mg_create_error = "asm_mg_params: struct_size does not match this library (initialise with asm_mg_params_default)";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (mp.n_coarse_cycles < 1 || (mp.intermediate_smoother != 0 && (mp.intermediate_cheb_degree < 1 ||
+                                 (mp.intermediate_precond_type != ASM_PRECOND_FDM && mp.intermediate_precond_type != ASM_PRECOND_DIAGONAL))))
+    {
+      g_mg_create_error = "n coarse cycles / mg intermediate smoother: invalid value";
+      return ASM_ERR_INVALID_VALUE;
+    }
   std::unique_ptr<asm_mg> holder(new asm_mg);
   asm_mg *                mg = holder.get();
   mg->mp                     = mp;
   mg->stream                 = (hipStream_t)fine->stream;
+  {
+    // the device of every level, before anything is created on it (a failure below destroys under this device too)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    mg->device = fine->device >= 0 ? fine->device : dev;
+  }
+  const DeviceGuard guard(mg->device);
   const auto fail            = [&](const int code, const std::string &msg) {
     g_mg_create_error = msg;
     asm_mg_destroy(holder.release());
@@ -1061,6 +1112,9 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
   const std::vector<LevelSpec> specs = level_sequence(*fine, mp);
   mg->levels.resize(specs.size());
   for (size_t l = 0; l < specs.size(); ++l)
+    if (specs[l].p == 1)
+      mg->intermediate_level = (int)l; // element_centered_preconditioners_01.cc:677-685
+  for (size_t l = 0; l < specs.size(); ++l)
     {
       Level &lv = mg->levels[l];
       lv.params = *fine;
@@ -1068,6 +1122,14 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
         lv.params.n_cells[d] = specs[l].nc[d];
       lv.params.degree = specs[l].p;
       lv.params.rank   = 0;
+      // "mg intermediate smoother" on the levels of the lower multigrid (include/multigrid.h:268-276)
+      if (mp.intermediate_smoother != 0 && (int)l >= 1 && (int)l <= mg->intermediate_level)
+        {
+          lv.params.precond_type = mp.intermediate_precond_type;
+          lv.params.cheb_degree  = mp.intermediate_cheb_degree;
+          if (mp.intermediate_precond_type == ASM_PRECOND_DIAGONAL)
+            lv.params.element_centric = 1;
+        }
       // the coarse CG solve is Jacobi-preconditioned; vertex-star patches need degree >= 2
       if ((l == 0 && mp.coarse_solver != ASM_MG_COARSE_SMOOTHER) || (lv.params.element_centric == 0 && specs[l].p < 2))
         {
@@ -1086,13 +1148,12 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
     }
   {
     asm_ctx *c0 = mg->levels[0].ctx;
-    int      dev = 0;
-    (void)hipGetDevice(&dev);
-    mg->device = fine->device >= 0 ? fine->device : dev;
     if (asm_vector_alloc(c0, &mg->cg_p) || asm_vector_alloc(c0, &mg->cg_z) || asm_vector_alloc(c0, &mg->cg_q))
       return fail(ASM_ERR_DEVICE, "coarse solver vector allocation failed");
+    asm_ctx *ci = mg->levels[mg->intermediate_level].ctx;
+    if (mp.n_coarse_cycles > 1 && (asm_vector_alloc(ci, &mg->rc_r) || asm_vector_alloc(ci, &mg->rc_d)))
+      return fail(ASM_ERR_DEVICE, "coarse cycle vector allocation failed");
   }
-  const DeviceGuard guard(mg->device);
   for (size_t l = 1; l < specs.size(); ++l)
     {
       Level &lv = mg->levels[l];
@@ -1134,6 +1195,15 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
           return fail(err, std::string("eigenvalue estimate on level ") + std::to_string(l) + ": " + asm_last_error(mg->levels[l].ctx));
       }
   *out = holder.release();
+  return ASM_OK;
+}
+
+int
+asm_mg_coarse_failures(const asm_mg *mg, int64_t *count)
+{
+  if (!mg || !count)
+    return ASM_ERR_INVALID_VALUE;
+  *count = mg->coarse_not_converged;
   return ASM_OK;
 }
 

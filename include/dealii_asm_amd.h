@@ -383,6 +383,18 @@ typedef struct asm_mg_params
   double  coarse_rel_tolerance;   /* ASM_MG_COARSE_CG */
   int32_t coarse_max_iterations;
   int32_t estimate_eigenvalues; /* 1: run asm_cheb_estimate_eigenvalues on every level at creation */
+  /* ---- ABI revision 3 (round 3): the two nested hierarchies of include/multigrid.h:260-375 ------------------
+   * The 'ph' / 'hp' level lists name the joint level twice (element_centered_preconditioners_01.cc:656-671); both copies
+   * are levels here too (identity transfer between them, a smoother each).  The levels up to the last one of degree 1
+   * ("intermediate level", :677-685) are smoothed by "mg intermediate smoother" and form the coarse-grid solver of the
+   * multigrid over the levels above, applied "n coarse cycles" times as a Richardson iteration (multigrid.h:346-365). */
+  int32_t n_coarse_cycles;            /* "n coarse cycles", default 1 (precondition.h:127) */
+  int32_t intermediate_smoother;      /* 0: "mg intermediate smoother" has no type = the mg smoother (precondition.h:148-158);
+                                         1: Chebyshev of the fields below */
+  int32_t intermediate_precond_type;  /* asm_precond_type of its inner preconditioner, e.g. ASM_PRECOND_DIAGONAL */
+  int32_t intermediate_cheb_degree;   /* its "degree" */
+  int32_t keep_duplicate_level;       /* default 1; 0: the joint level once (the hierarchy of ABI revisions 1-2) */
+  uint32_t struct_size;               /* set by asm_mg_params_default; asm_mg_create rejects any other value */
 } asm_mg_params;
 
 void asm_mg_params_default(asm_mg_params *p);
@@ -404,6 +416,10 @@ int asm_mg_restrict(asm_mg *mg, int32_t level, double *dst_coarse, const double 
 /* PreconditionMG::vmult (include/multigrid.h:466-472): one V-cycle from a zero initial guess; dst, src: vectors of
  * the finest level.  Pre-smoothing = smoother vmult, post-smoothing = smoother step (deal.II MGSmootherRelaxation) */
 int asm_mg_vmult(asm_mg *mg, double *dst, const double *src);
+/* Number of coarse-grid CG solves (ASM_MG_COARSE_CG) that ended at coarse_max_iterations without reaching
+ * coarse_rel_tolerance since the hierarchy was created: the V-cycles went on with an inexact coarse correction (the
+ * reference's AMG V-cycle, include/precondition.templates.h:592-613, is inexact by construction and reports nothing) */
+int asm_mg_coarse_failures(const asm_mg *mg, int64_t *count);
 
 /* solve(), element_centered_preconditioners_01.cc:108-263: SolverCG / SolverGMRES under ReductionControl */
 enum asm_solver_type

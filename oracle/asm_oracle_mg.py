@@ -95,9 +95,11 @@ def geometric_coarsening_sequence(nc):
     return seq[::-1]
 
 
-def level_sequence(nc, p, mg_type="h", p_sequence="bisect"):
-    """[(cells, degree)] from coarse to fine (element_centered_preconditioners_01.cc:640-672); a level that
-    would repeat its predecessor (the 'ph' / 'hp' lists of the reference name the joint level twice) is listed once"""
+def level_sequence(nc, p, mg_type="h", p_sequence="bisect", keep_duplicate=True):
+    """[(cells, degree)] from coarse to fine (element_centered_preconditioners_01.cc:640-672).  The 'ph' / 'hp' lists
+    of the reference name the joint level twice (ph: the finest mesh at the lowest degree, hp: the coarsest mesh at
+    the highest degree); both copies are levels of the hierarchy, with the identity as transfer between them and a
+    smoother each (keep_duplicate=False lists the level once: the hierarchy of rounds 1-2 of this build)."""
     degs = polynomial_coarsening_sequence(p, p_sequence)
     meshes = geometric_coarsening_sequence(nc)
     if mg_type == "h":
@@ -110,6 +112,8 @@ def level_sequence(nc, p, mg_type="h", p_sequence="bisect"):
         lv = [(m, degs[0]) for m in meshes] + [(meshes[-1], q) for q in degs]
     else:
         raise ValueError(f"Multigrid variant <{mg_type}> is not known!")
+    if keep_duplicate:
+        return lv
     out = []
     for l in lv:
         if not out or out[-1] != l:
@@ -117,29 +121,51 @@ def level_sequence(nc, p, mg_type="h", p_sequence="bisect"):
     return out
 
 
+def intermediate_level(seq):
+    """the last level of degree 1, else 0 (element_centered_preconditioners_01.cc:677-685): the levels up to it form
+    the "intermediate" multigrid (smoothed by "mg intermediate smoother"), which is the coarse-grid solver of the
+    multigrid over the levels above (include/multigrid.h:260-375)"""
+    il = 0
+    for l, (_, deg) in enumerate(seq):
+        if deg == 1:
+            il = l
+    return il
+
+
 class Multigrid:
     """One V-cycle as a preconditioner (PreconditionMG around deal.II's Multigrid::cycle):
     pre-smoothing = smoother.vmult (zero initial guess), post-smoothing = smoother.step
-    (MGSmootherRelaxation with one step), coarse level: coarse.vmult."""
+    (MGSmootherRelaxation with one step), coarse level: coarse.vmult.
+    Two nested hierarchies as in include/multigrid.h:260-375: the levels [0, il] (smoothers[1..il] are the
+    intermediate smoothers) are one multigrid, applied n_coarse_cycles times as a Richardson iteration
+    (SolverRelaxation under IterationNumberControl, multigrid.h:346-365) as the coarse-grid solver of the multigrid
+    over the levels [il, L]; with one cycle that is the flat recursion over all levels."""
 
-    def __init__(self, ops, smoothers, coarse, transfers, one_sided=False):
+    def __init__(self, ops, smoothers, coarse, transfers, one_sided=False, il=0, n_coarse_cycles=1):
         self.ops, self.smoothers, self.coarse, self.transfers, self.one_sided = ops, smoothers, coarse, transfers, one_sided
+        self.il, self.n_coarse_cycles = il, n_coarse_cycles
 
-    def _cycle(self, level, b):
+    def _cycle(self, level, b, top):
         if level == 0:
             return self.coarse.vmult(b)
+        if level == self.il and top and self.n_coarse_cycles > 1:
+            # coarse-grid solver of the upper multigrid: n Richardson steps preconditioned by the lower one
+            x = np.zeros_like(b)
+            for _ in range(self.n_coarse_cycles):
+                x = x + self._cycle(level, b - self.ops[level].vmult(x, unit_constrained=True), False)
+            return x
         op, sm = self.ops[level], self.smoothers[level]
         x = sm.vmult(b)
         r = b - op.vmult(x, unit_constrained=True)
         bc = self.transfers[level].restrict(r)
-        xc = self._cycle(level - 1, bc)
+        xc = self._cycle(level - 1, bc, True)
         x = x + self.transfers[level].prolongate(xc)
         if not self.one_sided:  # "one-sided v-cycle": identity post-smoother (include/multigrid.h:305-322)
             x = sm.step(x, b)
         return x
 
     def vmult(self, b, unit_constrained=True):
-        return self._cycle(len(self.ops) - 1, b)
+        return self._cycle(len(self.ops) - 1, b, True)
 
 
 class CoarseCG:
@@ -281,10 +307,12 @@ def right_hand_side_one(mesh: orc.Mesh):
 
 
 def build_multigrid(nc, p, bc, smoother_factory, coarse_factory, mg_type="h", p_sequence="bisect", mapfn=None, one_sided=False,
-                    extent=None):
-    """levels, operators, transfers and the V-cycle for a box mesh; smoother_factory(level, mesh, op) and
-    coarse_factory(mesh, op) return objects with vmult / step"""
-    seq = level_sequence(nc, p, mg_type, p_sequence)
+                    extent=None, intermediate_factory=None, n_coarse_cycles=1, keep_duplicate=True):
+    """levels, operators, transfers and the V-cycle for a box mesh; smoother_factory(level, mesh, op) ("mg smoother"),
+    intermediate_factory(level, mesh, op) ("mg intermediate smoother", default: the mg smoother,
+    include/precondition.h:140-160) and coarse_factory(mesh, op) return objects with vmult / step"""
+    seq = level_sequence(nc, p, mg_type, p_sequence, keep_duplicate)
+    il = intermediate_level(seq)
     dim = len(nc)
     meshes = []
     for cells, deg in seq:
@@ -292,6 +320,7 @@ def build_multigrid(nc, p, bc, smoother_factory, coarse_factory, mg_type="h", p_
         meshes.append(orc.Mesh(cells, deg, bc, h=h, mapfn=mapfn))
     ops = [orc.LaplaceOperator(m) for m in meshes]
     transfers = [None] + [Transfer(meshes[l], meshes[l - 1]) for l in range(1, len(meshes))]
-    smoothers = [None] + [smoother_factory(l, meshes[l], ops[l]) for l in range(1, len(meshes))]
+    inter = intermediate_factory or smoother_factory
+    smoothers = [None] + [(inter if l <= il else smoother_factory)(l, meshes[l], ops[l]) for l in range(1, len(meshes))]
     coarse = coarse_factory(meshes[0], ops[0])
-    return Multigrid(ops, smoothers, coarse, transfers, one_sided), meshes, ops
+    return Multigrid(ops, smoothers, coarse, transfers, one_sided, il, n_coarse_cycles), meshes, ops

@@ -17,13 +17,30 @@ def fine_params(pkg, nc, p, bc, geometry="cartesian", **kw):
 
 
 def oracle_hierarchy(nc, p, bc, mg_type, weighting, n_overlap, degree, lams, geometry="cartesian", coarse="smoother",
-                     coarse_rel_tol=1e-3, one_sided=False, p_sequence="bisect", polynomial_type="1st kind"):
+                     coarse_rel_tol=1e-3, one_sided=False, p_sequence="bisect", polynomial_type="1st kind", element_centric=True,
+                     intermediate=None, n_coarse_cycles=1, keep_duplicate=True):
+    """the oracle twin of asm_mg_create: "mg smoother" = Chebyshev(degree) over FDM on the levels above the intermediate
+    level, `intermediate` = (inner "FDM" | "Diagonal", Chebyshev degree) or None (= the mg smoother) on the levels up to
+    it; vertex-star patches become the diagonal smoother at degree 1 (as the library does)"""
     bcs = [BCMAP[b] for b in ([bc] * 3 if isinstance(bc, str) else bc)]
     mapfn = (lambda pts: orc.kershaw(0.3, 0.3, pts)) if geometry == "kershaw" else None
 
+    def cheb(level, op, prec, deg):
+        return orc.Chebyshev(op, prec, degree=deg, lambda_max=None if lams is None else lams[level], polynomial_type=polynomial_type)
+
     def smoother(level, mesh, op):
-        prec = orc.ASPoissonPreconditioner(mesh, n_overlap, weighting)
-        return orc.Chebyshev(op, prec, degree=degree, lambda_max=None if lams is None else lams[level], polynomial_type=polynomial_type)
+        if not element_centric and mesh.p < 2:
+            return cheb(level, op, orc.JacobiPreconditioner(op), degree)
+        return cheb(level, op, orc.ASPoissonPreconditioner(mesh, n_overlap, weighting, element_centric), degree)
+
+    def inter(level, mesh, op):
+        if intermediate is None:
+            return smoother(level, mesh, op)
+        if intermediate[0] == "Diagonal":
+            return cheb(level, op, orc.JacobiPreconditioner(op), intermediate[1])
+        if not element_centric and mesh.p < 2:
+            return cheb(level, op, orc.JacobiPreconditioner(op), intermediate[1])
+        return cheb(level, op, orc.ASPoissonPreconditioner(mesh, n_overlap, weighting, element_centric), intermediate[1])
 
     def coarse_factory(mesh, op):
         if coarse == "smoother":
@@ -33,7 +50,8 @@ def oracle_hierarchy(nc, p, bc, mg_type, weighting, n_overlap, degree, lams, geo
         return omg.CoarseCG(op, rel_tol=coarse_rel_tol)
 
     return omg.build_multigrid(nc, p, bcs, smoother, coarse_factory, mg_type=mg_type, p_sequence=p_sequence, mapfn=mapfn,
-                               one_sided=one_sided)
+                               one_sided=one_sided, intermediate_factory=inter, n_coarse_cycles=n_coarse_cycles,
+                               keep_duplicate=keep_duplicate)
 
 
 @pytest.mark.parametrize(
@@ -271,3 +289,106 @@ def test_gram_schmidt_sweeps(pkg, n_vec):
         assert abs(nn - ref @ ref) < 1e-12 * (ref @ ref)
         for v in [w] + vs:
             v.free()
+
+
+# ---- the hierarchies of the BASELINE configurations 3, 4, 5 (experiments/large-scaling-opt_{fdm2, fdmv, ras}.json): their
+#      smoothers inside the V-cycle and the preconditioned solve, 'ph' multigrid with the joint level kept twice and the
+#      "mg intermediate smoother" (Chebyshev(4) over the diagonal) of those files on the degree-1 levels
+CONFIG_HIERARCHIES = [
+    # id, nc, p, geometry, weighting, n_overlap, element_centric, Chebyshev degree, solver, intermediate smoother
+    ("config3_kershaw_p4_overlap2_post", (4, 4, 2), 4, "kershaw", "post", 2, True, 2, "GMRES", None),
+    ("config4_vertex_star_symm_cg", (4, 4, 4), 4, "cartesian", "symm", 1, False, 2, "CG", ("Diagonal", 4)),
+    ("config4_vertex_star_symm_kershaw", (4, 2, 2), 4, "kershaw", "symm", 1, False, 2, "CG", ("Diagonal", 4)),
+    ("config5_kershaw_p7_ras_overlap2_k3", (4, 2, 2), 7, "kershaw", "ras", 2, True, 3, "GMRES", ("Diagonal", 4)),
+    ("config5_cartesian_p7_ras_overlap2_k3", (4, 2, 2), 7, "cartesian", "ras", 2, True, 3, "GMRES", None),
+]
+
+
+@pytest.mark.parametrize("name,nc,p,geometry,weighting,n_overlap,element_centric,degree,solver,intermediate", CONFIG_HIERARCHIES,
+                         ids=[c[0] for c in CONFIG_HIERARCHIES])
+def test_v_cycle_and_solve_with_config_smoothers(pkg, name, nc, p, geometry, weighting, n_overlap, element_centric, degree, solver,
+                                                 intermediate):
+    """One V-cycle (fixed eigenvalue bounds on both sides) to 1e-11, and the preconditioned solve (direct coarse solver, own
+    eigenvalue estimates) with the oracle twin's iteration count, for the smoothers of BASELINE configs 3-5."""
+    prm = fine_params(pkg, nc, p, "dirichlet", geometry, weighting=weighting, n_overlap=n_overlap, element_centric=element_centric,
+                      cheb_degree=degree)
+    with pkg.Multigrid(prm, mg_type="ph", coarse="direct", estimate_eigenvalues=False, intermediate_smoother=intermediate) as mg:
+        lams = [1.2 + 0.07 * l for l in range(mg.n_levels)]
+        for l, c in enumerate(mg.levels):
+            c.set_eigenvalue(lams[l])
+        M, meshes, ops = oracle_hierarchy(nc, p, "dirichlet", "ph", weighting, n_overlap, degree, lams, geometry, coarse="direct",
+                                          element_centric=element_centric, intermediate=intermediate)
+        assert mg.n_levels == len(meshes)
+        b = np.random.default_rng(21).uniform(-1, 1, meshes[-1].n_dofs)
+        b[meshes[-1].constrained_mask()] = 0.0
+        bv, xv = mg.fine.vector(b), mg.fine.vector()
+        mg.vmult(xv, bv)
+        assert rel(xv.get(), M.vmult(b)) < 1e-11
+        bv.free()
+        xv.free()
+    with pkg.Multigrid(prm, mg_type="ph", coarse="direct", intermediate_smoother=intermediate) as mg:
+        M, meshes, ops = oracle_hierarchy(nc, p, "dirichlet", "ph", weighting, n_overlap, degree, None, geometry, coarse="direct",
+                                          element_centric=element_centric, intermediate=intermediate)
+        for l in range(1, mg.n_levels):
+            lam = mg.levels[l].cheb_parameters()["lambda_max"]
+            assert abs(lam - M.smoothers[l].lambda_hat) < 1e-7 * lam, (l, lam, M.smoothers[l].lambda_hat)
+        mesh, op = meshes[-1], ops[-1]
+        b = omg.right_hand_side_one(mesh)
+        fn = omg.solve_gmres if solver == "GMRES" else omg.solve_cg
+        x_ref, it_ref = fn(op, b, M, rel_tol=1e-6, abs_tol=0.0)
+        bv, xv = mg.fine.vector(b), mg.fine.vector()
+        res = mg.fine.solve(xv, bv, solver=solver, preconditioner="Multigrid", mg=mg, rel_tol=1e-6, abs_tol=0.0)
+        assert res.converged == 1 and res.n_iterations == it_ref, (res.n_iterations, it_ref)
+        assert rel(xv.get(), x_ref) < 1e-6
+        bv.free()
+        xv.free()
+
+
+@pytest.mark.parametrize("n_coarse_cycles,keep_duplicate", [(1, True), (2, True), (3, True), (1, False)])
+def test_nested_hierarchies(pkg, n_coarse_cycles, keep_duplicate):
+    """include/multigrid.h:260-375: the joint level of 'ph' twice (identity transfer), "mg intermediate smoother" on the
+    lower multigrid, "n coarse cycles" Richardson steps of it as the coarse-grid solver of the upper one"""
+    nc, p = (8, 4, 4), 4
+    inter = ("Diagonal", 4)
+    prm = fine_params(pkg, nc, p, "dirichlet", weighting="post", cheb_degree=2)
+    with pkg.Multigrid(prm, mg_type="ph", coarse="direct", estimate_eigenvalues=False, intermediate_smoother=inter,
+                       n_coarse_cycles=n_coarse_cycles, keep_duplicate_level=keep_duplicate) as mg:
+        lams = [1.25 + 0.05 * l for l in range(mg.n_levels)]
+        for l, c in enumerate(mg.levels):
+            c.set_eigenvalue(lams[l])
+        M, meshes, ops = oracle_hierarchy(nc, p, "dirichlet", "ph", "post", 1, 2, lams, coarse="direct", intermediate=inter,
+                                          n_coarse_cycles=n_coarse_cycles, keep_duplicate=keep_duplicate)
+        assert mg.n_levels == len(meshes) == (6 if keep_duplicate else 5)
+        if keep_duplicate:
+            # the two copies of the joint level: the transfer between them is the identity
+            l = M.il
+            assert meshes[l].n_dofs == meshes[l - 1].n_dofs
+            v = np.random.default_rng(4).uniform(-1, 1, meshes[l].n_dofs)
+            v[meshes[l].constrained_mask()] = 0.0
+            vc, vf = mg.levels[l - 1].vector(v), mg.levels[l].vector()
+            mg.prolongate_add(l, vf, vc)
+            assert rel(vf.get(), v) < 1e-14
+            mg.restrict(l, vc, vf)
+            assert rel(vc.get(), v) < 1e-14
+            vc.free()
+            vf.free()
+        b = np.random.default_rng(8).uniform(-1, 1, meshes[-1].n_dofs)
+        b[meshes[-1].constrained_mask()] = 0.0
+        bv, xv = mg.fine.vector(b), mg.fine.vector()
+        mg.vmult(xv, bv)
+        assert rel(xv.get(), M.vmult(b)) < 1e-11
+        bv.free()
+        xv.free()
+    # the solve with the levels' own eigenvalue estimates (the made-up bounds above need not give a contraction)
+    with pkg.Multigrid(prm, mg_type="ph", coarse="direct", intermediate_smoother=inter, n_coarse_cycles=n_coarse_cycles,
+                       keep_duplicate_level=keep_duplicate) as mg:
+        M, meshes, ops = oracle_hierarchy(nc, p, "dirichlet", "ph", "post", 1, 2, None, coarse="direct", intermediate=inter,
+                                          n_coarse_cycles=n_coarse_cycles, keep_duplicate=keep_duplicate)
+        b = omg.right_hand_side_one(meshes[-1])
+        x_ref, it_ref = omg.solve_gmres(ops[-1], b, M, rel_tol=1e-8, abs_tol=0.0)
+        bv, xv = mg.fine.vector(b), mg.fine.vector()
+        res = mg.fine.solve(xv, bv, solver="GMRES", preconditioner="Multigrid", mg=mg, rel_tol=1e-8, abs_tol=0.0)
+        assert res.converged == 1 and res.n_iterations == it_ref and it_ref < 30, (res.n_iterations, it_ref)
+        assert rel(xv.get(), x_ref) < 1e-7
+        bv.free()
+        xv.free()

@@ -106,8 +106,38 @@ def test_level_sequences():
     assert mg.polynomial_coarsening_sequence(4, "decrease by one") == [1, 2, 3, 4]
     assert mg.polynomial_coarsening_sequence(4, "go to one") == [1, 4]
     assert mg.level_sequence((8, 8), 3, "h") == [((1, 1), 3), ((2, 2), 3), ((4, 4), 3), ((8, 8), 3)]
-    assert mg.level_sequence((12, 12, 12), 4, "ph") == [((3, 3, 3), 1), ((6, 6, 6), 1), ((12, 12, 12), 1), ((12, 12, 12), 2), ((12, 12, 12), 4)]
+    # 'ph' / 'hp' name the joint level twice, as the reference's lists do (element_centered_preconditioners_01.cc:656-671);
+    # the last level of degree 1 is the top of the intermediate multigrid (:677-685)
+    ph = mg.level_sequence((12, 12, 12), 4, "ph")
+    assert ph == [((3, 3, 3), 1), ((6, 6, 6), 1), ((12, 12, 12), 1), ((12, 12, 12), 1), ((12, 12, 12), 2), ((12, 12, 12), 4)]
+    assert mg.intermediate_level(ph) == 3
+    hp = mg.level_sequence((4, 4), 4, "hp")
+    assert hp == [((1, 1), 1), ((1, 1), 2), ((1, 1), 4), ((1, 1), 4), ((2, 2), 4), ((4, 4), 4)]
+    assert mg.intermediate_level(hp) == 0
+    assert mg.level_sequence((12, 12, 12), 4, "ph", keep_duplicate=False) == [((3, 3, 3), 1), ((6, 6, 6), 1), ((12, 12, 12), 1), ((12, 12, 12), 2), ((12, 12, 12), 4)]
     assert mg.level_sequence((6, 6), 4, "p") == [((6, 6), 1), ((6, 6), 2), ((6, 6), 4)]
+    assert mg.intermediate_level(mg.level_sequence((6, 6), 4, "p")) == 0
+
+
+def test_duplicate_level_has_identity_transfer_and_nested_cycles():
+    """the transfer between the two copies of the joint level is the identity; n coarse cycles = n Richardson steps
+    preconditioned by the intermediate multigrid (include/multigrid.h:346-365)"""
+    bc = [orc.DIRICHLET] * 2
+    jac = lambda l, mesh, op: orc.Chebyshev(op, orc.JacobiPreconditioner(op), degree=4)
+    fdm = lambda l, mesh, op: orc.Chebyshev(op, orc.ASPoissonPreconditioner(mesh, 1, "post"), degree=2)
+    M, meshes, ops = mg.build_multigrid((12, 12), 4, bc, fdm, lambda mesh, op: mg.CoarseDirect(op), mg_type="ph", intermediate_factory=jac)
+    assert M.il == 3 and meshes[3].n_dofs == meshes[2].n_dofs
+    v = np.random.default_rng(3).uniform(-1, 1, meshes[3].n_dofs)
+    v[meshes[3].constrained_mask()] = 0
+    assert np.allclose(M.transfers[3].prolongate(v), v) and np.allclose(M.transfers[3].restrict(v), v)
+    b = mg.right_hand_side_one(meshes[-1])
+    _, it1 = mg.solve_cg(ops[-1], b, M, rel_tol=1e-8, abs_tol=0.0)
+    M2, _, _ = mg.build_multigrid((12, 12), 4, bc, fdm, lambda mesh, op: mg.CoarseDirect(op), mg_type="ph", intermediate_factory=jac, n_coarse_cycles=2)
+    _, it2 = mg.solve_cg(ops[-1], b, M2, rel_tol=1e-8, abs_tol=0.0)
+    M0, _, _ = mg.build_multigrid((12, 12), 4, bc, fdm, lambda mesh, op: mg.CoarseDirect(op), mg_type="ph", intermediate_factory=jac, keep_duplicate=False)
+    _, it0 = mg.solve_cg(ops[-1], b, M0, rel_tol=1e-8, abs_tol=0.0)
+    # (two coarse cycles make the V-cycle a non-symmetric preconditioner for CG: no monotone gain is asserted)
+    assert abs(it2 - it1) <= 2 and it1 <= it0 + 1 and it1 <= 20
 
 
 def test_v_cycle_with_cg_converges_3d():
