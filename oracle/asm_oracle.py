@@ -332,17 +332,23 @@ class LaplaceOperator:
         self.constrained = mesh.constrained_mask()
         self._setup_quadratic_geometry()
 
-    def _setup_quadratic_geometry(self):
-        mesh = self.mesh
+    @staticmethod
+    def q2_monomial_coefficients(mesh):
+        """nodal (0,1/2,1) -> monomial coefficients of the tri-quadratic map, direction by direction
+        (operator.h:625-658): c0 = x0, c1 = -3x0+4x1-x2, c2 = 2x0-4x1+2x2"""
         dim = mesh.dim
-        # nodal (0,1/2,1) -> monomial coefficients, direction by direction
-        # (operator.h:625-658): c0 = x0, c1 = -3x0+4x1-x2, c2 = 2x0-4x1+2x2
         C = np.array([[1.0, 0.0, 0.0], [-3.0, 4.0, -1.0], [2.0, -4.0, 2.0]])
         v = mesh.q2_pts
         for d in range(dim):
             ax = 1 + (dim - 1 - d)
             v = np.moveaxis(np.tensordot(v, C, axes=([ax], [1])), -1, ax)
-        self.q2_coeff = v  # (ncells, [3,]3,3, dim): X = sum v[k,j,i] x^i y^j z^k
+        return v  # (ncells, [3,]3,3, dim): X = sum v[k,j,i] x^i y^j z^k
+
+    def _setup_quadratic_geometry(self):
+        mesh = self.mesh
+        dim = mesh.dim
+        v = self.q2_monomial_coefficients(mesh)
+        self.q2_coeff = v
         xq, wq = mesh.basis.xq, mesh.basis.wq
         nq = len(xq)
         # Jacobian rows jac[d][e] = dX_e/dxi_d at all quadrature points (:1101-1128)
@@ -525,6 +531,54 @@ def fdm_eigen(M, K):
     return lam, Q  # Q[i, a]: component i of eigenvector a
 
 
+def fdm_eigen_batched(M, K):
+    """fdm_eigen for a stack of matrix pairs (..., m, m) at once (meshes whose cells all differ - Kershaw - have one
+    pair per cell and direction; a Python loop over them does not reach the sizes of the benchmarks): Cholesky
+    M = L L^T, symmetric eigen-problem of L^-1 K L^-T, Q = L^-T V, so that Q^T M Q = I as scipy.linalg.eigh(K, M)
+    normalises.  Signs of the eigenvectors may differ from fdm_eigen's; Q diag(.) Q^T does not depend on them."""
+    m = M.shape[-1]
+    con = np.einsum("...ii->...i", M) == 0.0
+    Mc, Kc = M.copy(), K.copy()
+    ii = np.arange(m)
+    Mc[..., ii, ii] = np.where(con, 1.0, Mc[..., ii, ii])
+    Kc[..., ii, ii] = np.where(con, 1.0, Kc[..., ii, ii])
+    L = np.linalg.cholesky(Mc)
+    Li = np.linalg.inv(L)
+    A = Li @ Kc @ np.swapaxes(Li, -1, -2)
+    A = 0.5 * (A + np.swapaxes(A, -1, -2))
+    lam, V = np.linalg.eigh(A)
+    Q = np.swapaxes(Li, -1, -2) @ V
+    Q = np.where(con[..., :, None], 0.0, Q)
+    return lam, Q
+
+
+def fdm_matrices_element_batched(b: "Basis1D", h3, lo_internal, lo_dirichlet, hi_internal, hi_dirichlet, n_overlap):
+    """fdm_matrices_element for arrays: h3 (..., 3), boolean arrays for the kind of the two faces"""
+    n1 = b.p + 1
+    m = n1 - 2 + 2 * n_overlap
+    shape = h3.shape[:-1]
+    M = np.zeros(shape + (m, m))
+    K = np.zeros(shape + (m, m))
+    o = n_overlap - 1
+    hs = h3[..., 1][..., None, None]
+    M[..., o : o + n1, o : o + n1] = b.M_ref * hs
+    K[..., o : o + n1, o : o + n1] = b.K_ref / hs
+    hl = np.where(lo_internal, h3[..., 0], 1.0)[..., None, None]
+    li = lo_internal[..., None, None]
+    M[..., :n_overlap, :n_overlap] += np.where(li, b.M_ref[n1 - n_overlap :, n1 - n_overlap :] * hl, 0.0)
+    K[..., :n_overlap, :n_overlap] += np.where(li, b.K_ref[n1 - n_overlap :, n1 - n_overlap :] / hl, 0.0)
+    keep = np.ones(shape + (m,))
+    keep[..., o] = np.where(lo_dirichlet, 0.0, 1.0)
+    s = n_overlap + n1 - 2
+    hr = np.where(hi_internal, h3[..., 2], 1.0)[..., None, None]
+    hi = hi_internal[..., None, None]
+    M[..., s:, s:] += np.where(hi, b.M_ref[:n_overlap, :n_overlap] * hr, 0.0)
+    K[..., s:, s:] += np.where(hi, b.K_ref[:n_overlap, :n_overlap] / hr, 0.0)
+    keep[..., s] = np.where(hi_dirichlet, 0.0, keep[..., s])
+    mask = keep[..., :, None] * keep[..., None, :]
+    return M * mask, K * mask
+
+
 class ASPoissonPreconditioner:
     """Restatement of ASPoissonPreconditioner (include/matrix_free.h:63-1568).
 
@@ -533,7 +587,9 @@ class ASPoissonPreconditioner:
     (m = 2p-1, :91; dof_tools.h:206-300).  weight_type in
     none|pre|post|symm|ras (restrictors.h:8-15)."""
 
-    def __init__(self, mesh: Mesh, n_overlap=1, weight_type="post", element_centric=True):
+    def __init__(self, mesh: Mesh, n_overlap=1, weight_type="post", element_centric=True, batched_eigen=None):
+        """batched_eigen: the eigen-decompositions of all cells at once (fdm_eigen_batched) instead of a loop with a cache
+        of distinct matrix pairs; default: on for element-centred patches of more than 4096 cells"""
         self.mesh = mesh
         p, dim = mesh.p, mesh.dim
         self.n_overlap = n_overlap = min(n_overlap, p)  # precondition.templates.h:195-196
@@ -558,7 +614,16 @@ class ASPoissonPreconditioner:
         lam = np.zeros((mesh.ncells, dim, m))
         Q = np.zeros((mesh.ncells, dim, m, m))
         cache = {}
-        for c in range(mesh.ncells):
+        if batched_eigen is None:
+            batched_eigen = element_centric and mesh.ncells > 4096
+        if batched_eigen:
+            assert element_centric
+            for d in range(dim):
+                lo_n, hi_n = mesh.neighbor(d, -1) >= 0, mesh.neighbor(d, +1) >= 0
+                Md, Kd = fdm_matrices_element_batched(b, ext[:, d], lo_n, ~lo_n & (mesh.bc[d][0] == DIRICHLET), hi_n,
+                                                      ~hi_n & (mesh.bc[d][1] == DIRICHLET), n_overlap)
+                lam[:, d], Q[:, d] = fdm_eigen_batched(Md, Kd)
+        for c in range(0 if batched_eigen else mesh.ncells):
             for d in range(dim):
                 if element_centric:
                     lo = "internal" if mesh.neighbor(d, -1)[c] >= 0 else mesh.bc[d][0]
@@ -576,7 +641,7 @@ class ASPoissonPreconditioner:
                     cache[key] = fdm_eigen(Md, Kd)
                 lam[c, d], Q[c, d] = cache[key]
         self.lam, self.Q = lam, Q
-        self.n_instances_1d = len(cache)
+        self.n_instances_1d = len(cache) if not batched_eigen else None
         self._setup_weights()
 
     def _setup_weights(self):

@@ -201,6 +201,33 @@ def test_full_size_bench_workload(pkg, nc, periodic, degree):
         assert rel(xv.get(), ref) < TOL
 
 
+@pytest.mark.parametrize("degree", [1, 2])
+def test_full_size_kershaw_workload(pkg, degree):
+    """BASELINE config 3 as worded (Kershaw eps = 0.3, p = 4, ~3e7 DoFs, FDM n_overlap = 1, post weights) at full size:
+    78^3 cells = 30 664 297 DoFs, one Chebyshev step against the threaded C++ restatement's deformed-mesh leg (checked
+    against the numpy oracle in tests/test_oracle_cpu_port.py; its per-cell tables come from the numpy oracle's array
+    code, the eigen-decompositions batched: tests/test_oracle_cpu_port.py::test_batched_eigen_decompositions)"""
+    import subprocess
+
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")],
+                   check=True, capture_output=True)
+    import asm_oracle_cpu
+
+    nc, lam = (78, 78, 78), 1.8
+    mesh = orc.Mesh(nc, 4, [orc.DIRICHLET] * 3, mapfn=lambda pts: orc.kershaw(0.3, 0.3, pts))
+    sm = asm_oracle_cpu.CpuSmootherDeformed(mesh, degree=degree, lambda_max=lam, n_threads=min(32, os.cpu_count() or 1))
+    rng = np.random.default_rng(7)
+    b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+    ref = sm.step(x0, b)
+    del sm, mesh
+    with pkg.Context(degree=4, n_cells=nc, boundary="dirichlet", geometry="kershaw", kershaw_eps=(0.3, 0.3), cheb_degree=degree) as ctx:
+        assert ctx.n_dofs == len(b)
+        ctx.set_eigenvalue(lam)
+        bv, xv = ctx.vector(b), ctx.vector(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), ref) < TOL
+
+
 # ---------------------------------------------------------------------------
 # "polynomial type" = "4th kind" (precondition.templates.h:135-152) and the fused vmult(dst, src, pre, post) surface
 # ---------------------------------------------------------------------------

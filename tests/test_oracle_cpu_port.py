@@ -54,3 +54,18 @@ def test_cpu_port_deformed_matches_numpy_oracle(cpu_mod, degree, threads):
     got = sm.step(x0, b)
     ref = cheb.step(x0, b)
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-12
+
+
+@pytest.mark.parametrize("n_overlap", [1, 2])
+@pytest.mark.parametrize("bc", ["dirichlet", "mixed"])
+def test_batched_eigen_decompositions(n_overlap, bc):
+    """the batched eigen-decompositions (large deformed meshes) give the same FDM inverse as the loop over cells"""
+    nc = (6, 3, 2)
+    bcs = [orc.DIRICHLET] * 3 if bc == "dirichlet" else [orc.DIRICHLET, orc.NEUMANN, orc.DIRICHLET]
+    mesh = orc.Mesh(nc, 4, bcs, mapfn=lambda pts: orc.kershaw(0.3, 0.3, pts))
+    a = orc.ASPoissonPreconditioner(mesh, n_overlap, "post", batched_eigen=False)
+    b = orc.ASPoissonPreconditioner(mesh, n_overlap, "post", batched_eigen=True)
+    v = np.random.default_rng(6).uniform(-1, 1, mesh.n_dofs)
+    ra, rb = a.vmult(v), b.vmult(v)
+    assert np.linalg.norm(ra - rb) < 1e-12 * np.linalg.norm(ra)
+    assert np.allclose(np.sort(a.lam, axis=-1), np.sort(b.lam, axis=-1), rtol=1e-10, atol=1e-9)
