@@ -182,6 +182,7 @@ EXPORTED_SYMBOLS = [
     "asm_debug_external_exchange",
     "asm_debug_two_phase",
     "asm_debug_loopback_init",
+    "asm_mg_debug_after_loopback",
     "asm_debug_exchange_all",
     "asm_profile_enable",
     "asm_profile_get",
@@ -203,6 +204,8 @@ EXPORTED_SYMBOLS = [
     "asm_mg_restrict",
     "asm_mg_vmult",
     "asm_mg_coarse_failures",
+    "asm_mg_comm_init",
+    "asm_mg_level_distributed",
     "asm_solver_params_default",
     "asm_solve",
 ]
@@ -280,6 +283,10 @@ def load_library():
     lib.asm_mg_prolongate_add.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.asm_mg_restrict.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.asm_mg_vmult.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.asm_mg_comm_init.argtypes = [C.c_void_p, C.c_char_p]
+    lib.asm_mg_level_distributed.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    lib.asm_mg_debug_after_loopback.argtypes = [C.c_void_p]
+    lib.asm_mg_coarse_failures.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.asm_solver_params_default.argtypes = [C.POINTER(AsmSolverParams)]
     lib.asm_solver_params_default.restype = None
     lib.asm_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(AsmSolverParams), C.c_void_p, C.c_void_p, C.POINTER(AsmSolverResult)]
@@ -682,6 +689,19 @@ class Multigrid:
             ch = C.c_void_p()
             self._check(self.lib.asm_mg_level_context(h, l, C.byref(ch)))
             self.levels.append(Context(_borrowed_handle=ch))
+
+    def level_distributed(self, level):
+        d = C.c_int32()
+        self._check(self.lib.asm_mg_level_distributed(self.handle, level, C.byref(d)))
+        return bool(d.value)
+
+    def comm_init(self, unique_id: bytes):
+        """asm_mg_comm_init: one RCCL communicator for all block-decomposed levels (collective)"""
+        self._check(self.lib.asm_mg_comm_init(self.handle, unique_id))
+
+    def after_loopback(self):
+        """testing aid (asm_mg_debug_after_loopback), from this rank's own thread"""
+        self._check(self.lib.asm_mg_debug_after_loopback(self.handle))
 
     def _check(self, err):
         if err:

@@ -41,6 +41,7 @@ struct LoopbackGroup
 {
   std::vector<asm_ctx *>  ranks;
   std::vector<double>     scalars;
+  std::vector<const double *> buffers; // all-reduce of device buffers (multigrid: replicated coarse levels)
   std::mutex              m;
   std::condition_variable cv;
   int                     waiting = 0, generation = 0;
@@ -83,6 +84,7 @@ struct asm_ctx
   double                   lambda_max = 0., theta = 0., delta = 0.;
   bool                     ev_set     = false;
   ncclComm_t               comm       = nullptr;
+  bool                     comm_shared = false; // the communicator belongs to another context (multigrid levels share the finest level's)
   std::shared_ptr<LoopbackGroup> loop; // testing aid, in place of comm
   double *                 hbuf[4]    = {nullptr, nullptr, nullptr, nullptr}; // send lo/hi, recv lo/hi
   long long                hbuf_size  = 0;
@@ -242,7 +244,7 @@ namespace
   // (include/matrix_free_internal.h:13-47); add = true runs the reverse
   // (import_from_ghosted_array with VectorOperation::add, :49-84) and zeroes
   // the ghost planes afterwards (:86-103).
-  int exchange_loopback(asm_ctx *ctx, double *v, hipStream_t st);
+  int exchange_loopback(asm_ctx *ctx, double *v, hipStream_t st, bool add = false);
 
   int
   exchange(asm_ctx *ctx, double *v, const bool add)
@@ -268,12 +270,12 @@ namespace
     const DevGrid &g = ctx->g;
     if (ctx->loop)
       {
-        if (add || ctx->n_dmsg == 0)
+        if (ctx->n_dmsg == 0)
           {
-            ctx->error = "the loopback group only carries the single-round ghost update";
+            ctx->error = "the loopback group only carries the single-round ghost update and its reverse";
             return ASM_ERR_NOT_SUPPORTED;
           }
-        return exchange_loopback(ctx, v, ctx->stream);
+        return exchange_loopback(ctx, v, ctx->stream, add);
       }
     if (!add && ctx->n_dmsg > 0)
       {
@@ -458,9 +460,40 @@ namespace
 
   // testing aid: the single-round ghost update through the loopback group (host-synchronous)
   int
-  exchange_loopback(asm_ctx *ctx, double *v, hipStream_t st)
+  exchange_loopback(asm_ctx *ctx, double *v, hipStream_t st, const bool add)
   {
     LoopbackGroup &lg = *ctx->loop;
+    if (add)
+      {
+        // compress(add): the single-round update run backwards (see exchange): ghost boxes -> their owners, added there
+        vec_boxes(ctx->g, 0, v, ctx->dbuf[1], ctx->drecv, st);
+        HIP_TRY(hipStreamSynchronize(st));
+        lg.barrier(); // every rank has packed its ghost boxes
+        for (int i = 0; i < ctx->n_dmsg; ++i)
+          {
+            const asm_direct_message &m = ctx->dmsg[i];
+            if (m.send_count == 0)
+              continue;
+            const asm_ctx *           pc = lg.ranks[m.peer];
+            const asm_direct_message *pm = nullptr;
+            for (int j = 0; j < pc->n_dmsg; ++j)
+              if (pc->dmsg[j].peer == ctx->s.prm.rank && pc->dmsg[j].offset[0] == -m.offset[0] && pc->dmsg[j].offset[1] == -m.offset[1] &&
+                  pc->dmsg[j].offset[2] == -m.offset[2])
+                pm = &pc->dmsg[j];
+            if (pm == nullptr || pm->recv_count != m.send_count)
+              {
+                ctx->error = "loopback exchange: send and receive boxes do not match";
+                return ASM_ERR_INVALID_VALUE;
+              }
+            HIP_TRY(hipMemcpyAsync(ctx->dbuf[0] + m.send_offset, pc->dbuf[1] + pm->recv_offset, m.send_count * sizeof(double),
+                                   hipMemcpyDeviceToDevice, st));
+          }
+        HIP_TRY(hipStreamSynchronize(st));
+        lg.barrier(); // every rank has read its neighbours' buffers
+        vec_boxes(ctx->g, 2, v, ctx->dbuf[0], ctx->dsend, st);
+        vec_boxes(ctx->g, 3, v, nullptr, ctx->drecv, st);
+        return ASM_OK;
+      }
     vec_boxes(ctx->g, 0, v, ctx->dbuf[0], ctx->dsend, st);
     HIP_TRY(hipStreamSynchronize(st));
     lg.barrier(); // every rank has packed
@@ -1497,7 +1530,7 @@ asm_destroy(asm_ctx *ctx)
           (void)hipStreamDestroy(ctx->bnd_stream);
         }
     }
-  if (ctx->comm)
+  if (ctx->comm && !ctx->comm_shared)
     ncclCommDestroy(ctx->comm);
   for (int k = 0; k < 2; ++k)
     for (auto &e : ctx->prof_events[k])
@@ -1552,6 +1585,7 @@ asm_debug_loopback_init(asm_ctx **ctxs, int n)
   auto lg = std::make_shared<LoopbackGroup>();
   lg->ranks.assign(ctxs, ctxs + n);
   lg->scalars.assign(n, 0.);
+  lg->buffers.assign(n, nullptr);
   for (int r = 0; r < n; ++r)
     {
       asm_ctx *ctx = ctxs[r];
@@ -1622,6 +1656,89 @@ asm_vector_free(asm_ctx *ctx, double *v)
   if (v == ctx->exchanged_vec)
     ctx->exchanged_vec = nullptr;
   HIP_TRY(hipFree(v));
+  return ASM_OK;
+}
+
+// ---- internal entry points of the multi-rank multigrid hierarchy (multigrid.hip; not part of the public interface) ----
+// update_ghost_values (add = 0) / compress(add) + zero_out_ghost_values (add = 1) of a level vector
+int
+asm_internal_exchange(asm_ctx *ctx, double *v, int add)
+{
+  const DeviceScope device_scope(ctx);
+  return exchange(ctx, v, add != 0);
+}
+
+// zero_out_ghost_values
+int
+asm_internal_zero_ghosts(asm_ctx *ctx, double *v)
+{
+  const DeviceScope device_scope(ctx);
+  if (multi_rank(ctx) && ctx->n_dmsg > 0)
+    vec_boxes(ctx->g, 3, v, nullptr, ctx->drecv, ctx->stream);
+  return launch_status(ctx, "zero ghosts");
+}
+
+// sum of the n doubles at v over the ranks of ctx's communicator, in place (a vector of a level that every rank holds whole)
+int
+asm_internal_allreduce(asm_ctx *ctx, double *v, long long n)
+{
+  const DeviceScope device_scope(ctx);
+  if (!multi_rank(ctx) || n <= 0)
+    return ASM_OK;
+  if (ctx->loop)
+    {
+      LoopbackGroup &lg = *ctx->loop;
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      lg.buffers[ctx->s.prm.rank] = v;
+      lg.barrier();
+      std::vector<double> sum((size_t)n, 0.), part((size_t)n);
+      for (const double *q : lg.buffers)
+        {
+          HIP_TRY(hipMemcpy(part.data(), q, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+          for (long long i = 0; i < n; ++i)
+            sum[(size_t)i] += part[(size_t)i];
+        }
+      lg.barrier(); // every rank has read every buffer
+      HIP_TRY(hipMemcpy(v, sum.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      return ASM_OK;
+    }
+  if (ctx->comm == nullptr)
+    {
+      ctx->error = "world_size > 1 but the hierarchy has no communicator (asm_mg_comm_init)";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (ctx->exchange_pending)
+    {
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_exchanged, 0));
+      ctx->exchange_pending = false;
+    }
+  NCCL_TRY(ncclAllReduce(v, v, (size_t)n, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+  return ASM_OK;
+}
+
+// the level contexts of a hierarchy use ONE communicator (the finest level's): operations of one communicator must not
+// be in flight on two streams, so none of them overlaps its exchange with a sweep (asm_comm_init of `src` may have
+// switched that on)
+int
+asm_internal_comm_share(asm_ctx *dst, asm_ctx *src)
+{
+  if (!multi_rank(dst))
+    return ASM_OK;
+  const DeviceScope device_scope(dst);
+  src->overlap = false;
+  if (dst != src)
+    {
+      if (dst->comm != nullptr || dst->loop)
+        {
+          dst->error = "the level context already has a communicator";
+          return ASM_ERR_INVALID_VALUE;
+        }
+      dst->comm        = src->comm;
+      dst->comm_shared = true;
+      dst->overlap     = false;
+    }
+  if (dst->s.prm.precond_type == ASM_PRECOND_DIAGONAL)
+    return asm_op_inverse_diagonal(dst, dst->inv_diag);
   return ASM_OK;
 }
 

@@ -247,12 +247,23 @@ namespace
     // intermediate boxes of the direction-by-direction transfer: [fine x][fine y][coarse z], [fine x][coarse y][coarse z]
     double *            pass_xy = nullptr, *pass_x = nullptr;
     std::vector<void *> allocs;
+    // Multi-rank hierarchies (include/multigrid.h:260-465 runs every level on the same partition): a level is block-
+    // decomposed by the fine level's process grid as long as the blocks stay nested (every rank's cells of the finer
+    // level are the children of its cells here); the levels below are held whole by every rank ("replicated": the
+    // same computation everywhere, as the reference's coarse levels shrink to a sub-communicator,
+    // element_centered_preconditioners_01.cc:592-633).
+    bool distributed = false;
   };
 } // namespace
 
 // context.hip: pool of solver work vectors of a context (not part of the public interface)
 extern "C" int  asm_work_vector_acquire(asm_ctx *ctx, double **v);
 extern "C" void asm_work_vector_release(asm_ctx *ctx, double *v);
+// context.hip: ghost exchange, all-reduce and communicator sharing of level contexts (multi-rank hierarchies)
+extern "C" int asm_internal_exchange(asm_ctx *ctx, double *v, int add);
+extern "C" int asm_internal_zero_ghosts(asm_ctx *ctx, double *v);
+extern "C" int asm_internal_allreduce(asm_ctx *ctx, double *v, long long n);
+extern "C" int asm_internal_comm_share(asm_ctx *dst, asm_ctx *src);
 
 struct asm_mg
 {
@@ -388,8 +399,19 @@ namespace
   }
 
   // 1-D interpolation tables between two levels in direction d (host), then uploaded
+  // The window of a level pair in direction d (one rank's part of the two levels; whole levels on one rank):
+  // fine rows [f_begin, f_begin + f_size) (global DoF coordinates: the rank's owned fine planes) and coarse
+  // rows [c_begin, c_begin + c_size) (the coarse planes the rank computes in a restriction: its owned ones and, below an
+  // interface, the plane it shares with the next rank, whose owner adds the two parts - compress(add)); coarse planes
+  // [c_store_begin, c_store_end) are stored on the rank (read by the prolongation: owned + ghost planes).
+  struct Window1D
+  {
+    int f_begin, f_size, c_begin, c_size, c_store_begin, c_store_end;
+  };
+
   bool
-  build_transfer_1d(Level &lv, const asm_params &pf, const asm_params &pc, const int d, Transfer1D &out, std::string &error)
+  build_transfer_1d(Level &lv, const asm_params &pf, const asm_params &pc, const int d, const Window1D &w, Transfer1D &out,
+                    std::string &error)
   {
     const int ncf = pf.n_cells[d], ncc = pc.n_cells[d], degf = pf.degree, degc = pc.degree;
     int       ratio = 1;
@@ -437,9 +459,10 @@ namespace
       for (int J = 0; J < nc; ++J)
         if (constrained(pf, nf, I) || constrained(pc, nc, J))
           P[(size_t)I * nc + J] = 0.;
-    std::vector<double> p_val((size_t)nf * MAX_N1C, 0.);
-    std::vector<int>    p_count(nf, 0);
-    for (int I = 0; I < nf; ++I)
+    // ---- tables of the window, in local logical coordinates (fine: relative to f_begin, coarse: relative to c_begin)
+    std::vector<double> p_val((size_t)w.f_size * MAX_N1C, 0.);
+    std::vector<int>    p_count(w.f_size, 0), p_start_w(w.f_size, 0);
+    for (int I = w.f_begin; I < w.f_begin + w.f_size; ++I)
       {
         int lo = n1c, hi = -1;
         for (int j = 0; j < n1c; ++j)
@@ -450,17 +473,24 @@ namespace
             }
         if (hi < lo)
           continue; // constrained row
-        p_start[I] += lo;
-        p_count[I] = hi - lo + 1;
-        for (int j = 0; j < p_count[I]; ++j)
-          p_val[(size_t)I * MAX_N1C + j] = P[(size_t)I * nc + p_start[I] + j];
+        const int st = p_start[I] + lo, li = I - w.f_begin;
+        if (st < w.c_store_begin || st + (hi - lo) >= w.c_store_end)
+          {
+            error = "transfer: a fine row of this rank needs coarse values it does not store (the levels' blocks are not nested)";
+            return false;
+          }
+        p_start_w[li] = st - w.c_begin;
+        p_count[li]   = hi - lo + 1;
+        for (int j = 0; j < p_count[li]; ++j)
+          p_val[(size_t)li * MAX_N1C + j] = P[(size_t)I * nc + st + j];
       }
-    std::vector<int>    r_start(nc, 0), r_count(nc, 0);
-    std::vector<double> r_val((size_t)nc * MAX_SUP, 0.);
-    for (int J = 0; J < nc; ++J)
+    // restriction: the fine rows of this rank only (every fine DoF is counted by its owner)
+    std::vector<int>    r_start(w.c_size, 0), r_count(w.c_size, 0);
+    std::vector<double> r_val((size_t)w.c_size * MAX_SUP, 0.);
+    for (int J = w.c_begin; J < w.c_begin + w.c_size; ++J)
       {
         int lo = nf, hi = -1;
-        for (int I = 0; I < nf; ++I)
+        for (int I = w.f_begin; I < w.f_begin + w.f_size; ++I)
           if (P[(size_t)I * nc + J] != 0.)
             {
               lo = std::min(lo, I);
@@ -473,15 +503,16 @@ namespace
             error = "transfer: support of a coarse basis function exceeds the table width";
             return false;
           }
-        r_start[J] = lo;
-        r_count[J] = hi - lo + 1;
+        const int lj = J - w.c_begin;
+        r_start[lj]  = lo - w.f_begin;
+        r_count[lj]  = hi - lo + 1;
         for (int I = lo; I <= hi; ++I)
-          r_val[(size_t)J * MAX_SUP + I - lo] = P[(size_t)I * nc + J];
+          r_val[(size_t)lj * MAX_SUP + I - lo] = P[(size_t)I * nc + J];
       }
-    out.n_fine   = nf;
-    out.n_coarse = nc;
+    out.n_fine   = w.f_size;
+    out.n_coarse = w.c_size;
     out.n1c      = n1c;
-    if (!upload(lv, p_start, &out.p_start) || !upload(lv, p_count, &out.p_count) || !upload(lv, p_val, &out.p_val) || !upload(lv, r_start, &out.r_start) ||
+    if (!upload(lv, p_start_w, &out.p_start) || !upload(lv, p_count, &out.p_count) || !upload(lv, p_val, &out.p_val) || !upload(lv, r_start, &out.r_start) ||
         !upload(lv, r_count, &out.r_count) || !upload(lv, r_val, &out.r_val))
       {
         error = "transfer: device allocation failed";
@@ -985,6 +1016,22 @@ namespace
       MG_CTX(mg, lv.ctx, asm_cheb_step(lv.ctx, x, b));                                   // post-smoothing
     return ASM_OK;
   }
+  int
+  estimate_level_eigenvalues(asm_mg *mg)
+  {
+    for (size_t l = 0; l < mg->levels.size(); ++l)
+      {
+        if (l == 0 && mg->mp.coarse_solver != ASM_MG_COARSE_SMOOTHER)
+          continue;
+        double lam = 0.;
+        if (const int err = asm_cheb_estimate_eigenvalues(mg->levels[l].ctx, &lam))
+          {
+            mg->error = std::string("eigenvalue estimate on level ") + std::to_string(l) + ": " + asm_last_error(mg->levels[l].ctx);
+            return err;
+          }
+      }
+    return ASM_OK;
+  }
 } // namespace
 
 extern "C" {
@@ -1067,10 +1114,10 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
     mp = *mp_in;
   else
     asm_mg_params_default(&mp);
-  if (fine->world_size != 1)
+  if (fine->world_size < 1 || fine->rank < 0 || fine->rank >= fine->world_size)
     {
-      g_mg_create_error = "multigrid level hierarchies are built on one rank only (world_size must be 1)";
-      return ASM_ERR_NOT_SUPPORTED;
+      g_mg_create_error = "multigrid: rank / world_size out of range";
+      return ASM_ERR_INVALID_VALUE;
     }
   if (mp.coarse_solver < ASM_MG_COARSE_SMOOTHER || mp.coarse_solver > ASM_MG_COARSE_DIRECT)
     {
@@ -1114,16 +1161,39 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
   for (size_t l = 0; l < specs.size(); ++l)
     if (specs[l].p == 1)
       mg->intermediate_level = (int)l; // element_centered_preconditioners_01.cc:677-685
-  for (size_t l = 0; l < specs.size(); ++l)
+  // ---- which levels are block-decomposed (multi-rank): from the finest level down while the blocks stay nested
+  const int L = (int)specs.size();
+  int       proc_grid[3] = {fine->proc_grid[0], fine->proc_grid[1], fine->proc_grid[2]};
+  for (int l = L - 1; l >= 0; --l) // finest level first: it fixes the process grid of the others
     {
       Level &lv = mg->levels[l];
       lv.params = *fine;
       for (int d = 0; d < 3; ++d)
         lv.params.n_cells[d] = specs[l].nc[d];
       lv.params.degree = specs[l].p;
-      lv.params.rank   = 0;
+      if (fine->world_size > 1)
+        {
+          bool dist = l == L - 1;
+          if (!dist && l > 0 && mg->levels[l + 1].distributed)
+            {
+              dist = true;
+              for (int d = 0; d < 3; ++d)
+                if (specs[l + 1].nc[d] != specs[l].nc[d] && specs[l + 1].nc[d] % (2 * proc_grid[d]) != 0)
+                  dist = false; // a rank's cells of level l + 1 are not the children of whole cells of this level
+            }
+          lv.distributed = dist;
+        }
+      if (lv.distributed)
+        for (int d = 0; d < 3; ++d)
+          lv.params.proc_grid[d] = proc_grid[d];
+      else
+        {
+          lv.params.rank       = 0;
+          lv.params.world_size = 1;
+          lv.params.proc_grid[0] = lv.params.proc_grid[1] = lv.params.proc_grid[2] = 0;
+        }
       // "mg intermediate smoother" on the levels of the lower multigrid (include/multigrid.h:268-276)
-      if (mp.intermediate_smoother != 0 && (int)l >= 1 && (int)l <= mg->intermediate_level)
+      if (mp.intermediate_smoother != 0 && l >= 1 && l <= mg->intermediate_level)
         {
           lv.params.precond_type = mp.intermediate_precond_type;
           lv.params.cheb_degree  = mp.intermediate_cheb_degree;
@@ -1136,13 +1206,16 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
           lv.params.precond_type    = ASM_PRECOND_DIAGONAL;
           lv.params.element_centric = 1; // (no patches are built for the diagonal smoother)
         }
-      if (l + 1 < specs.size())
+      if (l + 1 < L)
         lv.params.kernel_variant = ASM_KERNEL_AUTO; // a kernel family forced for the fine level need not exist on the others
       if (lv.params.geometry == ASM_GEOM_Q2_POINTS)
         return fail(ASM_ERR_NOT_SUPPORTED, "multigrid levels are generated for Cartesian and Kershaw geometry, not for caller-supplied points");
       if (const int err = asm_create(&lv.params, &lv.ctx))
         return fail(err, std::string("level ") + std::to_string(l) + ": " + asm_last_error(nullptr));
       (void)asm_vector_layout(lv.ctx, &lv.layout);
+      if (l == L - 1)
+        for (int d = 0; d < 3; ++d)
+          proc_grid[d] = lv.layout.proc_grid[d];
       if (asm_vector_alloc(lv.ctx, &lv.x) || asm_vector_alloc(lv.ctx, &lv.b) || asm_vector_alloc(lv.ctx, &lv.r))
         return fail(ASM_ERR_DEVICE, "level vector allocation failed");
     }
@@ -1157,14 +1230,25 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
   for (size_t l = 1; l < specs.size(); ++l)
     {
       Level &lv = mg->levels[l];
+      const Level &lc = mg->levels[l - 1];
+      lv.transfer.fine   = box_of(lv.layout);
+      lv.transfer.coarse = box_of(lc.layout);
       for (int d = 0; d < 3; ++d)
         {
+          // the rank's window of the level pair (whole levels on one rank)
+          Window1D w;
+          w.f_begin       = lv.layout.owned_begin[d];
+          w.f_size        = lv.layout.owned_size[d];
+          w.c_begin       = lc.layout.owned_begin[d];
+          const bool top_shared = lc.distributed && lc.layout.proc_coord[d] + 1 < lc.layout.proc_grid[d];
+          w.c_size        = lc.layout.owned_size[d] + (top_shared ? 1 : 0);
+          w.c_store_begin = lc.layout.owned_begin[d] + lc.layout.store_begin[d];
+          w.c_store_end   = w.c_store_begin + lc.layout.store_size[d];
+          lv.transfer.coarse.size[d] = w.c_size;
           std::string error;
-          if (!build_transfer_1d(lv, lv.params, mg->levels[l - 1].params, d, lv.transfer.d[d], error))
+          if (!build_transfer_1d(lv, lv.params, lc.params, d, w, lv.transfer.d[d], error))
             return fail(ASM_ERR_NOT_SUPPORTED, error);
         }
-      lv.transfer.fine   = box_of(lv.layout);
-      lv.transfer.coarse = box_of(mg->levels[l - 1].layout);
       // larger levels: one pass per direction (ASM_MG_DIRECT_TRANSFER keeps the single-kernel form everywhere)
       const TransferArgs &t = lv.transfer;
       if ((long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2] >= (1 << 17) &&
@@ -1179,22 +1263,62 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
           lv.pass_x  = lv.pass_xy + n_xy;
         }
     }
+  if (mp.coarse_solver == ASM_MG_COARSE_DIRECT && mg->levels[0].distributed)
+    return fail(ASM_ERR_NOT_SUPPORTED, "direct coarse-grid solver: the coarsest level of a multi-rank hierarchy must be a level of its own");
   if (mp.coarse_solver == ASM_MG_COARSE_DIRECT)
     {
       std::string error;
       if (const int err = build_coarse_inverse(mg, error))
         return fail(err, error);
     }
-  if (mp.estimate_eigenvalues)
-    for (size_t l = 0; l < specs.size(); ++l)
-      {
-        if (l == 0 && mp.coarse_solver != ASM_MG_COARSE_SMOOTHER)
-          continue;
-        double lam = 0.;
-        if (const int err = asm_cheb_estimate_eigenvalues(mg->levels[l].ctx, &lam))
-          return fail(err, std::string("eigenvalue estimate on level ") + std::to_string(l) + ": " + asm_last_error(mg->levels[l].ctx));
-      }
+  // (a multi-rank hierarchy estimates them once it has its communicator: asm_mg_comm_init)
+  if (mp.estimate_eigenvalues && fine->world_size == 1)
+    if (const int err = estimate_level_eigenvalues(mg))
+      return fail(err, mg->error);
   *out = holder.release();
+  return ASM_OK;
+}
+
+int
+asm_mg_comm_init(asm_mg *mg, const char id[128])
+{
+  if (!mg || mg->levels.empty())
+    return ASM_ERR_INVALID_VALUE;
+  const DeviceGuard guard(mg->device);
+  Level &           top = mg->levels.back();
+  if (!top.distributed)
+    {
+      mg->error = "asm_mg_comm_init: the hierarchy was created for a single rank (world_size = 1)";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  // ONE communicator (the finest level's) for every block-decomposed level
+  MG_CTX(mg, top.ctx, asm_comm_init(top.ctx, id));
+  for (Level &lv : mg->levels)
+    if (lv.distributed)
+      MG_CTX(mg, lv.ctx, asm_internal_comm_share(lv.ctx, top.ctx));
+  return mg->mp.estimate_eigenvalues ? estimate_level_eigenvalues(mg) : ASM_OK;
+}
+
+// testing aid: the level contexts have been given loopback groups (asm_debug_loopback_init per level, rank r = the
+// hierarchy of rank r); called by every rank's host thread: what asm_mg_comm_init does after the communicator exists
+int
+asm_mg_debug_after_loopback(asm_mg *mg)
+{
+  if (!mg || mg->levels.empty())
+    return ASM_ERR_INVALID_VALUE;
+  const DeviceGuard guard(mg->device);
+  for (Level &lv : mg->levels)
+    if (lv.distributed)
+      MG_CTX(mg, lv.ctx, asm_internal_comm_share(lv.ctx, lv.ctx)); // no overlapped exchange; the diagonal smoother's inverse diagonal
+  return mg->mp.estimate_eigenvalues ? estimate_level_eigenvalues(mg) : ASM_OK;
+}
+
+int
+asm_mg_level_distributed(const asm_mg *mg, int32_t level, int32_t *distributed)
+{
+  if (!mg || !distributed || level < 0 || level >= (int32_t)mg->levels.size())
+    return ASM_ERR_INVALID_VALUE;
+  *distributed = mg->levels[level].distributed ? 1 : 0;
   return ASM_OK;
 }
 
@@ -1237,6 +1361,10 @@ asm_mg_prolongate_add(asm_mg *mg, int32_t level, double *dst_fine, const double 
   const DeviceGuard   guard(mg->device);
   const TransferArgs &t = mg->levels[level].transfer;
   const long long     n = (long long)t.fine.size[0] * t.fine.size[1] * t.fine.size[2];
+  // a block-decomposed coarse level: the plane shared with the next rank (and whatever else the rows of this rank
+  // read) comes from its owner (update_ghost_values); a replicated one is whole on every rank
+  if (mg->levels[level - 1].distributed)
+    MG_CTX(mg, mg->levels[level - 1].ctx, asm_internal_exchange(mg->levels[level - 1].ctx, const_cast<double *>(src_coarse), 0));
   if (mg->levels[level].pass_xy)
     {
       // x, y, z: coarse -> [fine x][coarse y][coarse z] -> [fine x][fine y][coarse z] -> fine (+=)
@@ -1263,19 +1391,34 @@ asm_mg_restrict(asm_mg *mg, int32_t level, double *dst_coarse, const double *src
   const DeviceGuard   guard(mg->device);
   const TransferArgs &t = mg->levels[level].transfer;
   const long long     n = (long long)t.coarse.size[0] * t.coarse.size[1] * t.coarse.size[2];
-  if (mg->levels[level].pass_xy)
+  const Level &       lf = mg->levels[level], &lc = mg->levels[level - 1];
+  // Multi-rank: every rank sums over the fine DoFs it owns.  A block-decomposed coarse level: into its owned planes and
+  // the plane it shares with the next rank, which goes to its owner and is added there (compress(add); every other ghost
+  // entry must be zero for that).  A replicated coarse level below a block-decomposed fine one: into the whole level,
+  // summed over the ranks afterwards.
+  const bool junction = lf.distributed && !lc.distributed;
+  if (lc.distributed)
+    MG_CTX(mg, lc.ctx, asm_internal_zero_ghosts(lc.ctx, dst_coarse));
+  if (lf.pass_xy)
     {
       // z, y, x: fine -> [fine x][fine y][coarse z] -> [fine x][coarse y][coarse z] -> coarse
-      const Level &   lv = mg->levels[level];
       const BoxLayout bx = dense_box(t.fine.size[0], t.coarse.size[1], t.coarse.size[2]),
                       bxy = dense_box(t.fine.size[0], t.fine.size[1], t.coarse.size[2]);
-      launch_pass<false>(mg, restriction_pass(t, 2, t.fine, bxy), lv.pass_xy, src_fine);
-      launch_pass<false>(mg, restriction_pass(t, 1, bxy, bx), lv.pass_x, lv.pass_xy);
-      launch_pass<false>(mg, restriction_pass(t, 0, bx, t.coarse), dst_coarse, lv.pass_x);
-      return check_launch(mg, "restrict");
+      launch_pass<false>(mg, restriction_pass(t, 2, t.fine, bxy), lf.pass_xy, src_fine);
+      launch_pass<false>(mg, restriction_pass(t, 1, bxy, bx), lf.pass_x, lf.pass_xy);
+      launch_pass<false>(mg, restriction_pass(t, 0, bx, t.coarse), dst_coarse, lf.pass_x);
     }
-  hipLaunchKernelGGL(restrict_kernel, dim3(launch_blocks(n)), dim3(256), 0, mg->stream, t, dst_coarse, src_fine);
-  return check_launch(mg, "restrict");
+  else
+    hipLaunchKernelGGL(restrict_kernel, dim3(launch_blocks(n)), dim3(256), 0, mg->stream, t, dst_coarse, src_fine);
+  MG_TRY(check_launch(mg, "restrict"));
+  if (lc.distributed)
+    MG_CTX(mg, lc.ctx, asm_internal_exchange(lc.ctx, dst_coarse, 1));
+  else if (junction)
+    {
+      // (the padding of the rows is part of the allocation: whatever it holds is summed too and never read)
+      MG_CTX(mg, lf.ctx, asm_internal_allreduce(lf.ctx, dst_coarse, lc.layout.n_alloc));
+    }
+  return ASM_OK;
 }
 
 int

@@ -405,6 +405,16 @@ void asm_mg_params_default(asm_mg_params *p);
 int  asm_mg_create(const asm_params *fine, const asm_mg_params *mp, asm_mg **out);
 void asm_mg_destroy(asm_mg *mg);
 const char *asm_mg_last_error(const asm_mg *mg);
+/* Multi-rank hierarchies (fine->world_size > 1; every rank calls asm_mg_create with its rank): a level is block-decomposed
+ * by the fine level's process grid as long as every rank's cells of the finer level are the children of its cells there
+ * (always for p-coarsening; h-coarsening: cells per direction divisible by twice the ranks of that direction); the levels
+ * below - at least level 0 - are held whole by every rank.  Transfers exchange the coarse vector's shared planes
+ * (prolongation) or add the parts of the shared coarse planes at their owner (restriction; an all-reduce into the first
+ * replicated level), include/multigrid.h:289-346.  asm_mg_comm_init creates ONE RCCL communicator for all levels (collective,
+ * same unique id on every rank: asm_comm_unique_id) and then estimates the levels' eigenvalues (estimate_eigenvalues).
+ * Unmeasured between GPUs so far: verified with all ranks as contexts of one process (tests/test_gpu_partitioned_mg.py). */
+int asm_mg_comm_init(asm_mg *mg, const char id[128]);
+int asm_mg_level_distributed(const asm_mg *mg, int32_t level, int32_t *distributed);
 int asm_mg_n_levels(const asm_mg *mg, int32_t *n_levels);
 /* level 0 = coarsest; the context of level n_levels-1 is the fine operator the outer solver works on */
 int asm_mg_level_context(asm_mg *mg, int32_t level, asm_ctx **ctx);
@@ -477,6 +487,9 @@ int asm_debug_two_phase(asm_ctx *ctx, int on);
  * vmult/step/estimate run their multi-rank control flow (streams, events, launch phases, ghost
  * bookkeeping) with device copies + host barriers in place of RCCL */
 int asm_debug_loopback_init(asm_ctx **ctxs, int n);
+/* ... of a multi-rank multigrid hierarchy: after asm_debug_loopback_init on the contexts of every block-decomposed level
+ * (ctxs[r] = that level of rank r's hierarchy), every rank's host thread calls this in place of asm_mg_comm_init */
+int asm_mg_debug_after_loopback(asm_mg *mg);
 int asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add);
 
 #ifdef __cplusplus

@@ -225,8 +225,9 @@ def test_gmres_restart_and_left_preconditioning(pkg):
 def test_multigrid_refuses_what_it_does_not_cover(pkg):
     with pytest.raises(RuntimeError, match="non-periodic"):
         pkg.Multigrid(fine_params(pkg, (4, 4, 4), 4, "periodic"), mg_type="p")
-    with pytest.raises(RuntimeError, match="one rank"):
-        pkg.Multigrid(pkg.make_params(degree=2, n_cells=(4, 4, 4), world_size=2, rank=0))
+    with pytest.raises(RuntimeError, match="rank / world_size"):
+        pkg.Multigrid(pkg.make_params(degree=2, n_cells=(4, 4, 4), world_size=2, rank=2))
+    # (multi-rank hierarchies: tests/test_gpu_partitioned_mg.py)
 
 
 @pytest.mark.parametrize(
