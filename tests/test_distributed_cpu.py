@@ -231,3 +231,101 @@ def test_exchange_plan_gloo(case, world):
     for rank, ok_update, err in results:
         assert ok_update, f"rank {rank}: ghost values differ after update_ghost_values"
         assert err < 1e-13, f"rank {rank}: compress(add) result differs from the serial oracle by {err}"
+
+
+# ---------------------------------------------------------------------------
+# the exchange steps of the multi-rank multigrid transfers (csrc/multigrid.hip: asm_mg_restrict / asm_mg_prolongate_add):
+# every rank sums over the fine DoFs it owns into its owned coarse planes and the coarse plane it shares with the next
+# rank, compress(add) completes the shared planes at their owners; the prolongation reads the shared plane after
+# update_ghost_values.  Executed here on numpy boxes over gloo with the library's own plans of the two levels.
+# ---------------------------------------------------------------------------
+def _mg_worker(rank, world, port, case, result_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from conftest import load_package
+
+    pkg = load_package()
+    import asm_oracle as orc
+    import asm_oracle_mg as omg
+
+    (ncf, pf), (ncc, pc) = case
+    bcs = [orc.DIRICHLET] * 3
+    mf, mc = orc.Mesh(ncf, pf, bcs), orc.Mesh(ncc, pc, bcs)
+    T = omg.Transfer(mf, mc)
+    P1 = [omg.interpolation_1d(mf, mc, d) for d in range(3)]  # [fine, coarse] per direction
+    for P in P1:  # all faces Dirichlet: the first / last row and column belong to constrained DoFs (zero rows / columns)
+        P[0, :] = P[-1, :] = 0.0
+        P[:, 0] = P[:, -1] = 0.0
+    rng = np.random.default_rng(3)
+    rf, xc = rng.uniform(-1, 1, mf.n_dofs), rng.uniform(-1, 1, mc.n_dofs)
+    ref_restrict, ref_prolong = T.restrict(rf), T.prolongate(xc)
+    prm_f = pkg.make_params(degree=pf, n_cells=ncf, boundary="dirichlet", world_size=world, rank=rank, kernel="generic")
+    Lf = pkg.describe_layout(prm_f)
+    prm_c = pkg.make_params(degree=pc, n_cells=ncc, boundary="dirichlet", world_size=world, rank=rank, kernel="generic",
+                            proc_grid=tuple(Lf.proc_grid))
+    Lc = pkg.describe_layout(prm_c)
+    nuf, nuc = [mf.Nu[d] for d in range(3)], [mc.Nu[d] for d in range(3)]
+    gf = rf.reshape(nuf[2], nuf[1], nuf[0])
+    gxc = xc.reshape(nuc[2], nuc[1], nuc[0])
+
+    def ranges(L):
+        own = [(L.owned_begin[d], L.owned_begin[d] + L.owned_size[d]) for d in range(3)]
+        store = [(L.owned_begin[d] + L.store_begin[d], L.owned_begin[d] + L.store_begin[d] + L.store_size[d]) for d in range(3)]
+        return own, store
+
+    own_f, _ = ranges(Lf)
+    own_c, store_c = ranges(Lc)
+    # ---- restriction: partial sums over the owned fine DoFs, on the stored coarse box
+    loc_f = gf[own_f[2][0]:own_f[2][1], own_f[1][0]:own_f[1][1], own_f[0][0]:own_f[0][1]]
+    rows = [P1[d][own_f[d][0]:own_f[d][1], store_c[d][0]:store_c[d][1]] for d in range(3)]  # [fine owned, coarse stored]
+    part = np.einsum("kji,kc,jb,ia->cba", loc_f, rows[2], rows[1], rows[0])
+    # the library computes the owned planes and the shared top plane and zeroes every other ghost entry: the partial sums of
+    # those are zero by themselves (interior coarse basis functions vanish on the faces of their cell)
+    win = [(own_c[d][0], own_c[d][1] + (1 if Lc.proc_coord[d] + 1 < Lc.proc_grid[d] else 0)) for d in range(3)]
+    outside = np.ones(part.shape, bool)
+    outside[tuple(slice(win[d][0] - store_c[d][0], win[d][1] - store_c[d][0]) for d in (2, 1, 0))] = False
+    zero_outside = float(np.abs(part[outside]).max()) if outside.any() else 0.0
+    part[outside] = 0.0
+    _run_direct_compress(pkg.exchange_plan_direct(prm_c), part, Lc)
+    osl = tuple(slice(own_c[d][0] - store_c[d][0], own_c[d][1] - store_c[d][0]) for d in (2, 1, 0))
+    gsl = tuple(slice(own_c[d][0], own_c[d][1]) for d in (2, 1, 0))
+    err_r = float(np.abs(part[osl] - ref_restrict.reshape(nuc[2], nuc[1], nuc[0])[gsl]).max())
+    # ---- prolongation: owned coarse values, update_ghost_values, then the owned fine rows
+    box = np.full(part.shape, np.nan)
+    box[osl] = gxc[gsl]
+    _run_direct_plan(pkg.exchange_plan_direct(prm_c), box, Lc)
+    box = np.nan_to_num(box, nan=1e30)  # an entry the rows of this rank read but nobody filled would show
+    fine = np.einsum("cba,kc,jb,ia->kji", box, np.where(rows[2] != 0, rows[2], 0.0), np.where(rows[1] != 0, rows[1], 0.0),
+                     np.where(rows[0] != 0, rows[0], 0.0))
+    # (0 * 1e30 = 0: only entries with a non-zero weight count; a missing one gives ~1e30)
+    fsl = tuple(slice(own_f[d][0], own_f[d][1]) for d in (2, 1, 0))
+    err_p = float(np.abs(fine - ref_prolong.reshape(nuf[2], nuf[1], nuf[0])[fsl]).max())
+    result_q.put((rank, err_r, err_p, zero_outside))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("case", [(((4, 4, 4), 4), ((4, 4, 4), 2)), (((8, 4, 4), 2), ((4, 2, 2), 2)), (((4, 4, 8), 3), ((4, 4, 8), 1))],
+                         ids=["p4-p2", "h", "p3-p1"])
+def test_multigrid_transfer_exchange_gloo(case, world):
+    (ncf, _), (ncc, _) = case
+    if ncf != ncc and world > 2:
+        pytest.skip("the blocks of this level pair are nested for two ranks only")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + hash(str(case)) + world) % 2000
+    procs = [ctx.Process(target=_mg_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, err_r, err_p, zero_outside in results:
+        assert err_r < 1e-12, f"rank {rank}: restriction + compress(add) differs from the serial oracle by {err_r}"
+        assert err_p < 1e-12, f"rank {rank}: update_ghost_values + prolongation differs from the serial oracle by {err_p}"
+        assert zero_outside < 1e-14, f"rank {rank}: partial sums outside the restriction window are not zero ({zero_outside})"
