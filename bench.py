@@ -29,6 +29,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6  # MI355X vector fp64 peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2.4 GHz x 2)
+# fp64 operations per DoF of the deformed-cell (tri-quadratic) Laplace sweep, degree 4 (sum-factorised
+# evaluate + integrate 2 x 6 x 2 n1^4 per cell, Jacobian from 27 coefficient vectors, 3 x 3 inverse and two 3 x 3 products
+# per quadrature point; an estimate of the arithmetic the algorithm needs, not a count of issued instructions)
+KERSHAW_LAPLACE_FLOP_PER_DOF = 450.0
+NORTH_STAR_CELLS = (128, 128, 96)  # 100 860 545 DoFs at p = 4: the ~1e8-DoF point the north star is quoted on
 
 
 def algorithmic_bytes_per_dof(degree, what):
@@ -148,6 +154,7 @@ def main():
     ap.add_argument("--patch", default="cell", choices=["cell", "vertex"], help="element-centred or vertex-star patches")
     ap.add_argument("--weighting", default="post", choices=["none", "pre", "post", "symm", "ras"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the extra run at 128 x 128 x 96 cells (north_star_point)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = every core this process may use)")
     args = ap.parse_args()
 
@@ -176,6 +183,8 @@ def main():
 
         dist.init_process_group(backend="gloo")
 
+    default_workload = args.cells is None and args.workload == "cart_dirichlet" and args.degree == 1 and args.what == "cheb_step" \
+        and args.n_overlap == 1 and args.patch == "cell" and args.weighting == "post" and args.kernel == "auto"
     cells = args.cells
     if cells is None:
         cells = {"cart_dirichlet": (80, 80, 80), "cart_periodic": (128, 64, 64), "kershaw": (78, 78, 78)}[args.workload]
@@ -283,8 +292,13 @@ def main():
         except OSError:
             pass
         lap_variant = "generic" if args.workload == "kershaw" else ctx.kernel_variant()
+        # the deformed-cell Laplace sweep is bound by fp64 issue, not by memory (report the FLOP rate then)
+        fp64_bound = args.workload == "kershaw" and dom == "laplace"
+        if fp64_bound:
+            flops = KERSHAW_LAPLACE_FLOP_PER_DOF * ctx.n_owned
+            kernels["laplace"]["TFLOPps"] = flops / (kernels["laplace"]["avg_ms"] * 1e-3) / 1e12
         roofline = {
-            "bound": "hbm",
+            "bound": "fp64" if fp64_bound else "hbm",
             "kernel": {"laplace": f"Laplace sweep ({lap_variant})", "fdm": f"FDM Schwarz sweep ({ctx.kernel_variant()})"}[dom],
             "achieved": kernels[dom]["GBps"],
             "peak": HBM_PEAK_GBS,
@@ -295,6 +309,13 @@ def main():
             "avg_launch_ms": kernels[dom]["avg_ms"],
             "kernels": kernels,
         }
+        if fp64_bound:
+            roofline.update({"achieved": kernels["laplace"]["TFLOPps"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": kernels["laplace"]["TFLOPps"] / FP64_PEAK_TFLOPS,
+                             "hbm_frac": kernels["laplace"]["GBps"] / HBM_PEAK_GBS,
+                             "flop_per_dof": KERSHAW_LAPLACE_FLOP_PER_DOF})
+        for k in kernels.values():
+            k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
         total_bytes = (sum(a_sw) + sum(p_sw)) * n_dofs
         out = {
             "metric": "DoF/s per smoother application (Cheby+FDM, p=4, 3D)",
@@ -318,6 +339,7 @@ def main():
                 "cells_per_gpu": list(cells),
                 "proc_grid": grid,
                 "kernel_variant": ctx.kernel_variant(),
+                "laplace_rows": ctx.tiled_laplace_rows(),
                 "lambda_max_estimate": lam,
                 **({"rehearsal": "periodic directions closed by RCCL messages of the rank to itself"} if self_interface else {}),
             },
@@ -325,6 +347,41 @@ def main():
             "application_hbm_frac": total_bytes / world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
             "roofline": roofline,
         }
+        if world == 1:
+            # what a plain copy sustains on this device (read + written bytes; 1 GiB arrays, far beyond the 256 MiB Infinity
+            # Cache): the achievable HBM rate next to the 8 TB/s peak every fraction above is quoted against
+            b.free()
+            x.free()
+            out["peak_measured"] = {"copy_GBps": ctx.measure_copy_bandwidth(1 << 30, 5), "unit": "GB/s",
+                                    "kernel": "16-byte non-temporal copy, 4 loads in flight per lane, 2 x 1 GiB"}
+        if world == 1 and default_workload and not args.no_north_star:
+            # the size the north star is quoted on (p = 4, ~1e8 DoFs), same step, same accounting; the headline `value`
+            # stays on BASELINE config 2 (~3e7 DoFs) so that rounds compare
+            ctx.close()
+            ns = pkg.Context(degree=4, n_cells=NORTH_STAR_CELLS, boundary="dirichlet", geometry="cartesian",
+                             extent=(NORTH_STAR_CELLS[0] / NORTH_STAR_CELLS[2], NORTH_STAR_CELLS[1] / NORTH_STAR_CELLS[2], 1.0),
+                             precond="FDM", n_overlap=1, weighting="post", cheb_degree=1, device=local_rank)
+            nb, nx = ns.vector(np.ones(ns.n_owned)), ns.vector()
+            ns.set_eigenvalue(lam)
+            for _ in range(3):
+                ns.cheb_step(nx, nb)
+            ns.synchronize()
+            ns.profile_enable(True)
+            t1 = time.perf_counter()
+            ns_steps = 10
+            for _ in range(ns_steps):
+                ns.cheb_step(nx, nb)
+            ns.synchronize()
+            el = time.perf_counter() - t1
+            nk = {}
+            for name in ("laplace", "fdm"):
+                n, ms = ns.profile_get(name)
+                nk[name] = {"avg_ms": ms / n, "GBps": 24.0 * ns.n_owned / (ms / n * 1e-3) / 1e9,
+                            "hbm_frac": 24.0 * ns.n_owned / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out["north_star_point"] = {"cells": list(NORTH_STAR_CELLS), "n_dofs": ns.n_dofs, "steps": ns_steps,
+                                       "ms_per_step": el / ns_steps * 1e3, "value": ns.n_dofs * ns_steps / el, "unit": "DoF/s",
+                                       "laplace_rows": ns.tiled_laplace_rows(), "kernels": nk}
+            ns.close()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, pkg, cells)
         # the line the reference harness prints for the same run (matrix_free_loop_08.likwid.cc:390-395:
@@ -335,7 +392,7 @@ def main():
         print(f">> {label} {n_dofs} {args.steps * args.degree} {elapsed:.6e} 8 4 {int(ctx.layout.n_ghost)} {int(ctx.layout.n_ghost)}",
               file=sys.stderr)
         print(json.dumps(out))
-    ctx.close()
+    ctx.close()  # (idempotent)
     if world > 1:
         dist.destroy_process_group()
 

@@ -186,6 +186,8 @@ EXPORTED_SYMBOLS = [
     "asm_debug_exchange_all",
     "asm_profile_enable",
     "asm_profile_get",
+    "asm_measure_copy_bandwidth",
+    "asm_tiled_laplace_rows",
     "asm_vec_dot",
     "asm_vec_multi_dot",
     "asm_vec_multi_axpy_norm",
@@ -262,6 +264,8 @@ def load_library():
     lib.asm_debug_exchange_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int]
     lib.asm_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.asm_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    lib.asm_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+    lib.asm_tiled_laplace_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_vec_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.asm_vec_multi_dot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_double)]
     lib.asm_vec_multi_axpy_norm.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.c_int32,
@@ -649,6 +653,17 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         self._check(self.lib.asm_profile_get(self.handle, {"laplace": 0, "fdm": 1}[kernel], C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def measure_copy_bandwidth(self, bytes_per_array=1 << 30, reps=5):
+        """GB/s of a plain device-to-device copy (read + written bytes), asm_measure_copy_bandwidth"""
+        g = C.c_double()
+        self._check(self.lib.asm_measure_copy_bandwidth(self.handle, bytes_per_array, reps, C.byref(g)))
+        return g.value
+
+    def tiled_laplace_rows(self):
+        r = C.c_int32()
+        self._check(self.lib.asm_tiled_laplace_rows(self.handle, C.byref(r)))
+        return r.value
 
     def comm_init(self, unique_id: bytes):
         self._check(self.lib.asm_comm_init(self.handle, unique_id))

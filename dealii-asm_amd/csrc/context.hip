@@ -937,15 +937,25 @@ namespace
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    const int cand[4] = {0, 9, 10, 11};
-    float     ms_of[4];
+    const int  cand[4] = {0, 9, 10, 11};
+    float      ms_of[4];
+    const int *order_of[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; ++i)
       {
+        // every candidate with its own work order (kernels.h: tiled_order), as it would run
+        if (std::getenv("ASM_NO_TILED_ORDER") == nullptr)
+          {
+            std::vector<int> order;
+            tiled_order(ctx->g, ctx->n_cu, cand[i], order);
+            if (const int err = upload(ctx, order, &order_of[i]))
+              return err;
+          }
         // the residual form the Chebyshev iteration uses: dst = T, src = R, b = S (zero vectors)
         TiledArgs a{OP_RESIDUAL, ctx->R, ctx->T, ctx->S, nullptr, nullptr, 0., 0.};
         a.device = ctx->device;
         a.n_cu   = ctx->n_cu;
         a.rows   = cand[i];
+        a.order  = order_of[i];
         bool ok  = true;
         for (int rep = 0; rep < 2 && ok; ++rep) // warm-up (code object, caches, clocks)
           ok = laplace_tiled(ctx->g, ctx->op, a, ctx->stream);
@@ -959,14 +969,17 @@ namespace
         ms_of[i] = ok ? ms : 1e30f;
       }
     // the first-generation kernel unless another one is clearly (2 %) faster
-    int pick = 0;
+    int pick = 0, pick_i = 0;
     float best = ms_of[0];
     for (int i = 1; i < 4; ++i)
       if (ms_of[i] < 0.98f * ms_of[0] && ms_of[i] < best)
         {
-          best = ms_of[i];
-          pick = cand[i];
+          best   = ms_of[i];
+          pick   = cand[i];
+          pick_i = i;
         }
+    ctx->order_a = order_of[pick_i];
+    ctx->order_p = order_of[0]; // (the FDM sweep is the first-generation kernel: same tiling as candidate 0)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ctx->laplace_rows = pick;
@@ -1484,15 +1497,13 @@ asm_create(const asm_params *p, asm_ctx **out)
     return fail(err);
   // single-phase tiled sweeps: the workgroups at Dirichlet faces first (kernels.h: tiled_order); ASM_NO_TILED_ORDER keeps
   // the launch positions (experiments)
-  if ((ctx->s.laplace_tiled || ctx->s.fdm_tiled) && std::getenv("ASM_NO_TILED_ORDER") == nullptr)
+  // (tune_tiled_laplace has set the tables of a context that measures its candidates; the others:)
+  if ((ctx->s.laplace_tiled || ctx->s.fdm_tiled) && std::getenv("ASM_NO_TILED_ORDER") == nullptr && ctx->order_p == nullptr)
     {
       std::vector<int> order;
-      if (ctx->s.fdm_tiled || ctx->laplace_rows == 0)
-        {
-          tiled_order(ctx->g, ctx->n_cu, 0, order);
-          if ((err = upload(ctx, order, &ctx->order_p)))
-            return fail(err);
-        }
+      tiled_order(ctx->g, ctx->n_cu, 0, order);
+      if ((err = upload(ctx, order, &ctx->order_p)))
+        return fail(err);
       ctx->order_a = ctx->order_p;
       if (ctx->s.laplace_tiled && ctx->laplace_rows != 0)
         {
@@ -2216,6 +2227,70 @@ asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms)
     }
   *launches = (int64_t)ctx->prof_used[kernel];
   *total_ms = sum;
+  return ASM_OK;
+}
+
+// which tiled Laplace sweep the context uses: cell rows (waves) per workgroup, 8 = first generation, 9-11 = second
+// (measured at creation or fixed by ASM_TILED_ROWS); 0 = the context has no tiled Laplace sweep
+int
+asm_tiled_laplace_rows(const asm_ctx *ctx, int32_t *rows)
+{
+  if (!ctx || !rows)
+    return ASM_ERR_INVALID_VALUE;
+  *rows = ctx->s.laplace_tiled ? (ctx->laplace_rows == 0 ? 8 : ctx->laplace_rows) : 0;
+  return ASM_OK;
+}
+
+// measurement aid of bench.py ("peak_measured"): the rate of a plain device-to-device copy of two arrays of `bytes` bytes
+// each (read + written bytes per second, best of `reps` launches after one warm-up), allocated and freed here
+int
+asm_measure_copy_bandwidth(asm_ctx *ctx, int64_t bytes, int32_t reps, double *gb_per_s)
+{
+  const DeviceScope device_scope(ctx);
+  if (bytes < (1 << 20) || reps < 1 || gb_per_s == nullptr)
+    {
+      ctx->error = "asm_measure_copy_bandwidth: at least 1 MiB per array and one repetition";
+      return ASM_ERR_INVALID_VALUE;
+    }
+  void *a = nullptr, *b = nullptr;
+  if (hipMalloc(&a, (size_t)bytes) != hipSuccess || hipMalloc(&b, (size_t)bytes) != hipSuccess)
+    {
+      (void)hipFree(a);
+      (void)hipGetLastError();
+      ctx->error = "asm_measure_copy_bandwidth: allocation failed";
+      return ASM_ERR_DEVICE;
+    }
+  hipEvent_t e0, e1;
+  int        err = ASM_OK;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    err = ASM_ERR_DEVICE;
+  float best = 1e30f;
+  if (!err)
+    {
+      (void)hipMemsetAsync(a, 1, (size_t)bytes, ctx->stream);
+      (void)hipMemsetAsync(b, 0, (size_t)bytes, ctx->stream);
+      for (int r = 0; r <= reps && !err; ++r)
+        {
+          (void)hipEventRecord(e0, ctx->stream);
+          vec_stream_copy(b, a, bytes / 16, ctx->stream);
+          (void)hipEventRecord(e1, ctx->stream);
+          float ms = 0.f;
+          if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)
+            err = ASM_ERR_DEVICE;
+          else if (r > 0 && ms < best)
+            best = ms;
+        }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (err)
+    {
+      ctx->error = "asm_measure_copy_bandwidth: device error";
+      return err;
+    }
+  *gb_per_s = 2.0 * (double)(bytes / 16 * 16) / (best * 1e-3) / 1e9;
   return ASM_OK;
 }
 

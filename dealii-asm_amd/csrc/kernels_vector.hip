@@ -466,4 +466,30 @@ namespace asmamd
       largest = std::max(largest, (long long)boxes.size[b][0] * boxes.size[b][1] * boxes.size[b][2]);
     hipLaunchKernelGGL(boxes_kernel, dim3(grid_for(largest, 4), boxes.n), dim3(VB), 0, st, g, mode, vec, buf, boxes);
   }
+  namespace
+  {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __global__ void __launch_bounds__(256)
+    stream_copy_kernel(v4f *__restrict__ dst, const v4f *__restrict__ src, const long long n)
+    {
+      const long long i = blockIdx.x * 1024ll + threadIdx.x;
+      v4f             v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 256ll * u < n)
+          v[u] = __builtin_nontemporal_load(src + i + 256ll * u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 256ll * u < n)
+          __builtin_nontemporal_store(v[u], dst + i + 256ll * u);
+    }
+  } // namespace
+
+  void
+  vec_stream_copy(void *dst, const void *src, const long long n_vec16, hipStream_t st)
+  {
+    const long long blocks = (n_vec16 + 1023) / 1024;
+    if (blocks > 0 && blocks < (1ll << 31))
+      hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (v4f *)dst, (const v4f *)src, n_vec16);
+  }
 } // namespace asmamd

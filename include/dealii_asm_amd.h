@@ -331,6 +331,13 @@ int asm_synchronize(asm_ctx *ctx);
  * matrix_free_loop_08.likwid.cc:365-377 are the reference's counterpart) */
 int asm_profile_enable(asm_ctx *ctx, int on);
 int asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
+/* Measurement aid ("peak_measured" of bench.py): rate of a plain device-to-device copy between two arrays of `bytes` bytes
+ * (allocated and freed by the call; read + written bytes per second, best of `reps` launches): what the device sustains
+ * next to the 8 TB/s HBM peak the roofline fractions are quoted against */
+int asm_measure_copy_bandwidth(asm_ctx *ctx, int64_t bytes, int32_t reps, double *gb_per_s);
+/* Cell rows (waves) per workgroup of the context's tiled Laplace sweep: 8 = first generation, 9 / 10 / 11 = second
+ * (picked by a measurement at creation, or ASM_TILED_ROWS); 0 = no tiled Laplace sweep.  Reported by bench.py. */
+int asm_tiled_laplace_rows(const asm_ctx *ctx, int32_t *rows);
 /* timing helper for benchmarks: runs `reps` back-to-back calls of one entry
  * point between two HIP events on the context's stream and returns the
  * elapsed milliseconds.  what: 0 op_vmult, 1 precond_vmult, 2 cheb_vmult, 3 cheb_step */
