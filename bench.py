@@ -66,14 +66,27 @@ def cpu_baseline(args, pkg, cells):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
+    # ... and the CPU time the control group grants (cgroup v2 cpu.max "quota period"): a GPU box shows all 256 hardware
+    # threads of its host but is throttled to 16 CPUs' worth of time, so that more threads than that run SLOWER
+    # (profiles/r03_cpu_baseline_threads.txt: 3.9e8 DoF/s at 16 threads, 1.6e8 at 256)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(q) // int(period))
+    except (OSError, ValueError):
+        pass
+    granted = min(usable, quota) if quota else usable
     if args.workload != "kershaw":
         import asm_oracle_cpu
 
-        threads = max(1, usable if args.cpu_threads <= 0 else min(usable, args.cpu_threads))
+        threads = max(1, granted if args.cpu_threads <= 0 else min(usable, args.cpu_threads))
         nc = tuple(cells)  # the mesh of the GPU measurement itself
-        sm = asm_oracle_cpu.CpuSmoother(nc, args.workload == "cart_periodic", degree=args.degree, lambda_max=1.7, n_threads=threads)
-        b = np.ones(sm.n_dofs)
+        lib = asm_oracle_cpu.native_library()  # built here, on the host it runs on, with -march=native
+        native = "native" in os.path.basename(lib)
+        sm = asm_oracle_cpu.CpuSmoother(nc, args.workload == "cart_periodic", degree=args.degree, lambda_max=1.7, n_threads=threads, lib=lib)
         # each call sets up its thread pool and first-touches its work vectors: several steps per call
+        b = np.ones(sm.n_dofs)
         x = sm.step(np.zeros(sm.n_dofs), b, reps=2)  # warm-up
         per_call = 8
         reps, t0 = 0, time.perf_counter()
@@ -90,19 +103,26 @@ def cpu_baseline(args, pkg, cells):
             "kind": "port",
             "host_cpu_count": os.cpu_count(),
             "host_cpus_usable": usable,
+            "host_cpu_quota": quota,
             "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} cells p=4 "
-            f"({sm.n_dofs} DoFs, the bench mesh), C++ restatement oracle/asm_oracle_cpu.cc, {threads} threads "
-            f"(os.cpu_count()={os.cpu_count()}, usable={usable})",
+            f"({sm.n_dofs} DoFs, the bench mesh), C++ restatement oracle/asm_oracle_cpu.cc "
+            f"({'-march=native' if native else '-march=x86-64-v3'}; blocks of 8x4x4 cells per thread and colour, SIMD batches of 8 cells), "
+            f"{threads} threads (os.cpu_count()={os.cpu_count()}, usable={usable}, cgroup cpu quota={quota})",
+            # the reference's own published solve (data/data.pdf Table 8: Kershaw eps=1 p=4, 7.19e6 DoFs, 4 GMRES iterations,
+            # 9.52e-2 s on 40 MPI ranks, Chebyshev k=1) implies, with ~2 fine-level smoother steps per V-cycle plus the
+            # coarser levels, roughly 1e9 DoF/s per fine-level smoother step: a DERIVED figure for other hardware, quoted
+            # for scale only
+            "reference_derived": {"value": 1.0e9, "unit": "DoF/s", "basis": "data/data.pdf Table 8, 40 MPI ranks ('gold'), derived"},
         }
     # Kershaw: the threaded C++ restatement with per-cell tri-quadratic geometry and eigen-decompositions (checked
     # against the numpy oracle in tests/test_oracle_cpu_port.py); its tables come from the numpy oracle, whose setup
     # loops over the cells in Python, hence the smaller sample mesh
     import asm_oracle_cpu
 
-    threads = max(1, usable if args.cpu_threads <= 0 else min(usable, args.cpu_threads))
+    threads = max(1, granted if args.cpu_threads <= 0 else min(usable, args.cpu_threads))
     nc = (24, 24, 24)
     mesh = orc.Mesh(nc, 4, [orc.DIRICHLET] * 3, mapfn=lambda pts: orc.kershaw(0.3, 0.3, pts))
-    sm = asm_oracle_cpu.CpuSmootherDeformed(mesh, degree=args.degree, lambda_max=1.8, n_threads=threads)
+    sm = asm_oracle_cpu.CpuSmootherDeformed(mesh, degree=args.degree, lambda_max=1.8, n_threads=threads, lib=asm_oracle_cpu.native_library())
     b = np.ones(mesh.n_dofs)
     x = sm.step(np.zeros(mesh.n_dofs), b, reps=2)  # warm-up
     per_call = 16
@@ -120,6 +140,7 @@ def cpu_baseline(args, pkg, cells):
         "kind": "port",
         "host_cpu_count": os.cpu_count(),
         "host_cpus_usable": usable,
+        "host_cpu_quota": quota,
         "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} Kershaw cells p=4 "
         f"({mesh.n_dofs} DoFs), C++ restatement oracle/asm_oracle_cpu.cc (deformed-cell leg), {threads} threads",
     }

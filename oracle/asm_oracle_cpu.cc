@@ -13,10 +13,14 @@
 //   * P: gather -> 3 sweeps with Q^T, scaling by 1/(lx+ly+lz), 3 sweeps with Q, weights,
 //     scatter-add (cell_operation_normal, include/matrix_free.h:1023-1062);
 //   * Chebyshev updates as in PreconditionChebyshev (deal.II) for the first-kind polynomial;
-//   * threads take cells of one colour (2x2x2 parity) at a time, the shared-memory
-//     counterpart of the reference's one-MPI-rank-per-core runs.
+//   * threads take whole BLOCKS of cells (8 x 4 x 4) of one colour at a time (2x2x2 parity of the blocks: blocks of
+//     a colour share no DoF), the cells of a block one after the other in SIMD batches of 8 consecutive cells along x:
+//     a block's DoFs (76 KB per vector) stay in the core's cache, a batch row is 33 consecutive DoFs.  This is the
+//     shared-memory counterpart of the reference's one-MPI-rank-per-core runs with its cell batches
+//     (round 3; rounds 1-2 coloured single cells with stride 2: every gather a strided one, 1.3e8 DoF/s on 256 threads).
 // Tables (1-D basis, eigen-decompositions, weights) are computed by oracle/asm_oracle.py
 // and passed in, so this file contains the sweeps only.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -127,16 +131,76 @@ namespace
         }
   }
 
+  // same with the lanes' matrices interleaved: Qb[i * 5 + a][v]
+  template <bool FWD>
+  inline void
+  sweep_qb(const double (*Qb)[VL], const int d, double (*t)[VL])
+  {
+    const int stride = d == 0 ? 1 : (d == 1 ? N1 : N1 * N1);
+    for (int o2 = 0; o2 < N1; ++o2)
+      for (int o1 = 0; o1 < N1; ++o1)
+        {
+          const int base = d == 0 ? (o2 * N1 + o1) * N1 : (d == 1 ? o2 * N1 * N1 + o1 : o2 * N1 + o1);
+          double    in[N1][VL], out[N1][VL];
+          for (int i = 0; i < N1; ++i)
+            for (int v = 0; v < VL; ++v)
+              in[i][v] = t[base + i * stride][v];
+          for (int a = 0; a < N1; ++a)
+            {
+              for (int v = 0; v < VL; ++v)
+                out[a][v] = 0.;
+              for (int i = 0; i < N1; ++i)
+                for (int v = 0; v < VL; ++v)
+                  out[a][v] += (FWD ? Qb[i * N1 + a][v] : Qb[a * N1 + i][v]) * in[i][v];
+            }
+          for (int i = 0; i < N1; ++i)
+            for (int v = 0; v < VL; ++v)
+              t[base + i * stride][v] = out[i][v];
+        }
+  }
+
   struct Batch
   {
     int  n;            // active lanes
     int  c[VL][3];     // cell coordinates
+    bool x_run = false; // the lanes are consecutive cells along x
   };
+
+  // lanes are consecutive cells along x (same y, z) and the row does not wrap: 4 n + 1 consecutive DoFs per (j, k)
+  inline bool
+  contiguous_batch(const Problem &p, const Batch &bt)
+  {
+    return bt.x_run && (!p.periodic[0] || bt.c[0][0] + bt.n < p.nc[0]);
+  }
 
   template <bool MASK>
   inline void
   gather(const Problem &p, const Batch &bt, const double *src, double (*t)[VL])
   {
+    if (contiguous_batch(p, bt))
+      {
+        const int I0 = P * bt.c[0][0], nrow = P * bt.n + 1;
+        for (int k = 0; k < N1; ++k)
+          for (int j = 0; j < N1; ++j)
+            {
+              const int  J = P * bt.c[0][1] + j, K = P * bt.c[0][2] + k;
+              const bool row_con = MASK && (constrained(p, 1, J) || constrained(p, 2, K));
+              double     row[P * VL + 1];
+              const double *s = src + dof(p, I0, J, K);
+              for (int i = 0; i < nrow; ++i)
+                row[i] = row_con ? 0. : s[i];
+              for (int i = nrow; i < P * VL + 1; ++i)
+                row[i] = 0.;
+              if (MASK && constrained(p, 0, I0))
+                row[0] = 0.;
+              if (MASK && constrained(p, 0, I0 + nrow - 1))
+                row[nrow - 1] = 0.;
+              for (int i = 0; i < N1; ++i)
+                for (int v = 0; v < VL; ++v)
+                  t[(k * N1 + j) * N1 + i][v] = v < bt.n ? row[P * v + i] : 0.;
+            }
+        return;
+      }
     for (int k = 0; k < N1; ++k)
       for (int j = 0; j < N1; ++j)
         for (int i = 0; i < N1; ++i)
@@ -156,6 +220,28 @@ namespace
   inline void
   scatter_add(const Problem &p, const Batch &bt, const double (*t)[VL], double *dst, const double sign)
   {
+    if (contiguous_batch(p, bt))
+      {
+        const int I0 = P * bt.c[0][0], nrow = P * bt.n + 1;
+        for (int k = 0; k < N1; ++k)
+          for (int j = 0; j < N1; ++j)
+            {
+              const int J = P * bt.c[0][1] + j, K = P * bt.c[0][2] + k;
+              if (constrained(p, 1, J) || constrained(p, 2, K))
+                continue;
+              // the lanes' rows overlap in their end points: summed first, one update per DoF
+              double row[P * VL + 1];
+              for (int i = 0; i < P * VL + 1; ++i)
+                row[i] = 0.;
+              for (int v = 0; v < bt.n; ++v)
+                for (int i = 0; i < N1; ++i)
+                  row[P * v + i] += t[(k * N1 + j) * N1 + i][v];
+              double *d = dst + dof(p, I0, J, K);
+              for (int i = (constrained(p, 0, I0) ? 1 : 0); i < nrow - (constrained(p, 0, I0 + nrow - 1) ? 1 : 0); ++i)
+                d[i] += sign * row[i];
+            }
+        return;
+      }
     for (int k = 0; k < N1; ++k)
       for (int j = 0; j < N1; ++j)
         for (int i = 0; i < N1; ++i)
@@ -305,15 +391,22 @@ namespace
           lam[d][v] = Q[d][v] + 25;
           w[d][v]   = p.cell_eig ? nullptr : p.wpost[d] + (long)c * N1;
         }
+    // the lanes' matrices side by side ([entry][lane]), as TensorProductMatrixSymmetricSum keeps them for a cell batch:
+    // the sweeps then read one SIMD vector per entry
+    alignas(64) double Qb[3][25][VL];
     for (int d = 0; d < 3; ++d)
-      sweep_q<true>(Q[d], d, t);
+      for (int e = 0; e < 25; ++e)
+        for (int v = 0; v < VL; ++v)
+          Qb[d][e][v] = Q[d][v][e];
+    for (int d = 0; d < 3; ++d)
+      sweep_qb<true>(Qb[d], d, t);
     for (int k = 0; k < N1; ++k)
       for (int j = 0; j < N1; ++j)
         for (int i = 0; i < N1; ++i)
           for (int v = 0; v < VL; ++v)
             t[(k * N1 + j) * N1 + i][v] /= lam[0][v][i] + (lam[1][v][j] + lam[2][v][k]);
     for (int d = 0; d < 3; ++d)
-      sweep_q<false>(Q[d], d, t);
+      sweep_qb<false>(Qb[d], d, t);
     if (p.cell_eig)
       {
         for (int v = 0; v < VL; ++v)
@@ -412,47 +505,75 @@ namespace
     bool                            stop_ = false;
   };
 
-  // cells of one colour (2x2x2 parity: no two cells of a colour share a DoF), in SIMD batches along x,
-  // ordered by z layer; thread t takes the t-th slice of the list
-  std::vector<Batch>
-  colour_batches(const Problem &p, const int colour)
+  // Blocks of BS[0] x BS[1] x BS[2] cells; colour = 2x2x2 parity of the block coordinates: no two blocks of a colour
+  // share a DoF (a periodic direction needs an even number of blocks: its block size is reduced until it has).  The cells
+  // of a block in SIMD batches of up to 8 consecutive cells along x, layer by layer; blocks ordered by z, so that thread
+  // t's slice of the blocks is the t-th slab of the mesh (and of the vectors it first touched).
+  struct ColourBlocks
   {
-    std::vector<Batch> batches;
-    for (int cz = (colour >> 2) & 1; cz < p.nc[2]; cz += 2)
-      for (int cy = (colour >> 1) & 1; cy < p.nc[1]; cy += 2)
-        {
-          Batch bt;
-          bt.n = 0;
-          for (int cx = colour & 1; cx < p.nc[0]; cx += 2)
-            {
-              bt.c[bt.n][0] = cx;
-              bt.c[bt.n][1] = cy;
-              bt.c[bt.n][2] = cz;
-              if (++bt.n == VL)
+    std::vector<Batch>  batches;
+    std::vector<size_t> block_begin; // batches [block_begin[b], block_begin[b + 1]) = block b
+  };
+  ColourBlocks
+  colour_blocks(const Problem &p, const int colour)
+  {
+    int bs[3] = {VL, 4, 4}, nb[3];
+    for (int d = 0; d < 3; ++d)
+      {
+        while (true)
+          {
+            nb[d] = (p.nc[d] + bs[d] - 1) / bs[d];
+            if (!p.periodic[d] || nb[d] % 2 == 0 || bs[d] == 1)
+              break;
+            --bs[d];
+          }
+      }
+    ColourBlocks cb;
+    for (int bz = (colour >> 2) & 1; bz < nb[2]; bz += 2)
+      for (int by = (colour >> 1) & 1; by < nb[1]; by += 2)
+        for (int bx = colour & 1; bx < nb[0]; bx += 2)
+          {
+            cb.block_begin.push_back(cb.batches.size());
+            for (int cz = bz * bs[2]; cz < std::min((bz + 1) * bs[2], p.nc[2]); ++cz)
+              for (int cy = by * bs[1]; cy < std::min((by + 1) * bs[1], p.nc[1]); ++cy)
                 {
-                  batches.push_back(bt);
-                  bt.n = 0;
+                  Batch bt;
+                  bt.n     = 0;
+                  bt.x_run = true;
+                  for (int cx = bx * bs[0]; cx < std::min((bx + 1) * bs[0], p.nc[0]); ++cx)
+                    {
+                      bt.c[bt.n][0] = cx;
+                      bt.c[bt.n][1] = cy;
+                      bt.c[bt.n][2] = cz;
+                      if (++bt.n == VL)
+                        {
+                          cb.batches.push_back(bt);
+                          bt.n = 0;
+                        }
+                    }
+                  if (bt.n)
+                    cb.batches.push_back(bt);
                 }
-            }
-          if (bt.n)
-            batches.push_back(bt);
-        }
-    return batches;
+          }
+    cb.block_begin.push_back(cb.batches.size());
+    return cb;
   }
 
   // run f(batch) over all cells, colour by colour, batches split over the pool's threads
   template <typename F>
   void
-  cell_loop(Pool &pool, const std::vector<Batch> (&colours)[8], F &&f)
+  cell_loop(Pool &pool, const ColourBlocks (&colours)[8], F &&f)
   {
     const int nt = pool.size();
     for (int colour = 0; colour < 8; ++colour)
       {
-        const std::vector<Batch> &batches = colours[colour];
-        const size_t              nb      = batches.size();
+        const ColourBlocks &cb = colours[colour];
+        const size_t        nb = cb.block_begin.size() - 1; // whole blocks per thread
+        if (nb == 0)
+          continue;
         pool.run([&](const int th) {
-          for (size_t i = nb * th / nt; i < nb * (th + 1) / nt; ++i)
-            f(batches[i]);
+          for (size_t i = cb.block_begin[nb * th / nt]; i < cb.block_begin[nb * (th + 1) / nt]; ++i)
+            f(cb.batches[i]);
         });
       }
   }
@@ -475,9 +596,9 @@ namespace
   {
   const long n = (long)p.nu[0] * p.nu[1] * p.nu[2];
   Pool               pool(n_threads < 1 ? 1 : n_threads);
-  std::vector<Batch> colours[8];
+  ColourBlocks colours[8];
   for (int c = 0; c < 8; ++c)
-    colours[c] = colour_batches(p, c);
+    colours[c] = colour_blocks(p, c);
   // work vectors: uninitialised allocations, first touched by the thread that owns the slice
   const auto alloc = [&](const long count) { return static_cast<double *>(std::malloc(sizeof(double) * count)); };
   double *   xw = alloc(n), *bw = alloc(n), *r = alloc(n), *t = alloc(n), *xo = alloc(n);
@@ -566,7 +687,7 @@ namespace
         p.nu[d]       = nc[d] * P + (periodic[d] ? 0 : 1);
         p.h[d]        = h[d];
         if (periodic[d] && (nc[d] % 2))
-          return 1; // the 2x2x2 colouring needs an even number of cells in periodic directions
+          return 1; // the 2x2x2 colouring of the blocks needs an even number of cells in periodic directions
       }
     return 0;
   }

@@ -11,6 +11,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_build", "liboracle_cpu.so")
 
 
+def native_library():
+    """the C++ restatement built with -march=native ON THIS MACHINE (bench.py's cpu_baseline), or the
+    portable build if that fails.  The file name carries a hash of the CPU's model and flags: a build made on another
+    machine (the snapshot travels) is not mistaken for this one's."""
+    import hashlib
+    import subprocess
+
+    try:
+        info = [l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags"))][:2]
+        tag = hashlib.sha1("".join(info).encode()).hexdigest()[:12]
+        subprocess.run(["make", "-C", HERE, "native", f"NATIVE_TAG={tag}"], check=True, capture_output=True, timeout=300)
+        path = os.path.join(HERE, "_build", f"liboracle_cpu_native_{tag}.so")
+        C.CDLL(path)
+        return path
+    except Exception:  # noqa: BLE001 - any failure: the portable build
+        return LIB
+
+
 def _ptr(a, t=C.c_double):
     return a.ctypes.data_as(C.POINTER(t))
 
@@ -18,10 +36,10 @@ def _ptr(a, t=C.c_double):
 class CpuSmoother:
     """Chebyshev(k) + FDM (n_overlap=1, post weights) on a Cartesian box, degree 4."""
 
-    def __init__(self, nc, periodic, extent=(1.0, 1.0, 1.0), degree=3, lambda_max=1.8, smoothing_range=20.0, n_threads=1):
-        if not os.path.exists(LIB):
-            raise RuntimeError(f"{LIB} missing: run `make -C oracle`")
-        self.lib = C.CDLL(LIB)
+    def __init__(self, nc, periodic, extent=(1.0, 1.0, 1.0), degree=3, lambda_max=1.8, smoothing_range=20.0, n_threads=1, lib=None):
+        if not os.path.exists(lib or LIB):
+            raise RuntimeError(f"{lib or LIB} missing: run `make -C oracle`")
+        self.lib = C.CDLL(lib or LIB)
         self.nc = np.array(nc, dtype=np.int32)
         self.periodic = np.array([1 if periodic else 0] * 3, dtype=np.int32)
         self.h = np.array([extent[d] / nc[d] for d in range(3)], dtype=np.float64)
@@ -82,11 +100,11 @@ class CpuSmootherDeformed:
     them array operations, the eigen-decompositions batched for large meshes: the 78^3-cell mesh of the benchmarks is
     within reach)."""
 
-    def __init__(self, mesh, degree=3, lambda_max=1.8, smoothing_range=20.0, n_threads=1):
-        if not os.path.exists(LIB):
-            raise RuntimeError(f"{LIB} missing: run `make -C oracle`")
+    def __init__(self, mesh, degree=3, lambda_max=1.8, smoothing_range=20.0, n_threads=1, lib=None):
+        if not os.path.exists(lib or LIB):
+            raise RuntimeError(f"{lib or LIB} missing: run `make -C oracle`")
         assert mesh.p == 4 and mesh.dim == 3 and not any(mesh.periodic)
-        self.lib = C.CDLL(LIB)
+        self.lib = C.CDLL(lib or LIB)
         self.nc = np.array(mesh.nc, dtype=np.int32)
         self.degree, self.n_threads, self.n_dofs = degree, n_threads, mesh.n_dofs
         max_ev = 1.2 * lambda_max
