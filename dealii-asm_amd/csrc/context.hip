@@ -719,6 +719,24 @@ namespace
     if (dst == ctx->exchanged_vec)
       ctx->exchanged_vec = nullptr;
     FdmFused fu;
+    if (ctx->f.s7_flag[0] != nullptr && !multi_rank(ctx))
+      {
+        // 7^3 patches, one rank: patch results summed in LDS along z, the vector update applied with the store
+        fu.mode  = mode;
+        fu.x     = x;
+        fu.x_old = x_old;
+        fu.f1    = f1;
+        fu.f2    = f2;
+        prof_mark(ctx, 1, true);
+        const bool ok = fdm_slice7_acc(ctx->g, ctx->f, src, dst, fu, ctx->stream);
+        prof_mark(ctx, 1, false);
+        if (!ok)
+          {
+            ctx->error = "accumulating 7^3 FDM kernel not available for this configuration";
+            return ASM_ERR_NOT_SUPPORTED;
+          }
+        return ASM_OK;
+      }
     if (ctx->patch_tmp != nullptr && !multi_rank(ctx))
       {
         // one rank: the kernel that sums the patch results per DoF applies the vector update as well
@@ -1406,6 +1424,57 @@ asm_create(const asm_params *p, asm_ctx **out)
               f.s7_on     = 2;
             }
         }
+      // accumulate form of the 7^3 sweep (kernels.h: fdm_slice7_acc), one rank: which DoF planes belong to one column /
+      // z chunk of the box alone
+      f.s7_flag[0] = f.s7_flag[1] = f.s7_flag[2] = nullptr;
+      f.s7_lz                                    = 0;
+      if (f.s7_on && f.origin_mul == 4 && s.prm.world_size == 1 && s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_S7_TMP") == nullptr)
+        {
+          const int n2 = f.s7_hi[2] - f.s7_lo[2];
+          const int columns = ((f.s7_hi[0] - f.s7_lo[0] + S7_TILE_X - 1) / S7_TILE_X) * ((f.s7_hi[1] - f.s7_lo[1] + S7_TILE_Y - 1) / S7_TILE_Y);
+          // about eight workgroups per compute unit (two are resident), chunks of at least six layers (a chunk shares
+          // three of its 4 lz + 3 DoF planes with the next)
+          const int want = (8 * std::max(ctx->n_cu, 1) + columns - 1) / columns;
+          int       lz   = std::max(6, (n2 + want - 1) / want);
+          if (const char *e = std::getenv("ASM_S7_LZ"))
+            lz = std::max(1, std::atoi(e));
+          f.s7_lz = std::min(lz, n2);
+          for (int d = 0; d < 3; ++d)
+            {
+              const int                  n_store = s.g.wrap[d] ? s.g.nc[d] * s.g.p : s.g.ext_hi[d] - s.g.ext_lo[d] + 1;
+              const int                  T = d == 0 ? S7_TILE_X : (d == 1 ? S7_TILE_Y : f.s7_lz), none = -(1 << 30);
+              std::vector<int>           owner(n_store, none), coord(n_store, 0);
+              std::vector<unsigned char> multi(n_store, 0), flag(n_store, 1);
+              for (int c = 0; c < s.g.nc[d]; ++c)
+                {
+                  const int unit = (c >= f.s7_lo[d] && c < f.s7_hi[d]) ? (c - f.s7_lo[d]) / T : -1 - c;
+                  for (int pos = 0; pos < 7; ++pos)
+                    {
+                      const int I = f.origin_mul * c + f.origin_add + pos;
+                      if (!s.g.exists(d, I))
+                        continue;
+                      const int si = s.g.store_index(d, I);
+                      if (owner[si] == none)
+                        {
+                          owner[si] = unit;
+                          coord[si] = I;
+                        }
+                      else if (owner[si] != unit || coord[si] != I) // (a periodic direction meets itself around the block)
+                        multi[si] = 1;
+                    }
+                }
+              for (int si = 0; si < n_store; ++si)
+                flag[si] = !(owner[si] >= 0 && !multi[si]);
+              if (!s.g.wrap[d])
+                {
+                  if (s.g.dir_lo[d])
+                    flag[0 - s.g.ext_lo[d]] = 1;
+                  if (s.g.dir_hi[d])
+                    flag[s.g.nc[d] * s.g.p - s.g.ext_lo[d]] = 1;
+                }
+              UP(flag, &f.s7_flag[d]);
+            }
+        }
     }
 #undef UP
   if (alloc_vec(ctx, &ctx->R) || alloc_vec(ctx, &ctx->T) || alloc_vec(ctx, &ctx->S))
@@ -1416,7 +1485,8 @@ asm_create(const asm_params *p, asm_ctx **out)
   // (restricted additive Schwarz keeps the atomics: only a patch's own DoFs have a non-zero weight,
   // so a sixth of the entries is added and the atomic form is the faster one - measured)
   ctx->ras_direct = std::getenv("ASM_RAS_ATOMICS") == nullptr;
-  if (s.prm.precond_type == ASM_PRECOND_FDM && !s.fdm_tiled && s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_FDM_ATOMICS") == nullptr)
+  if (s.prm.precond_type == ASM_PRECOND_FDM && !s.fdm_tiled && s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_FDM_ATOMICS") == nullptr &&
+      ctx->f.s7_flag[0] == nullptr)
     {
       // patch results of the generic FDM sweep; without it (allocation failure) the sweep adds with atomics
       const size_t bytes = (size_t)s.g.nc[0] * s.g.nc[1] * s.g.nc[2] * s.m * s.m * s.m * sizeof(double);

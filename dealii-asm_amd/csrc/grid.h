@@ -81,6 +81,9 @@ namespace asmamd
     return xcd * (n >> 3) + (xcd < (n & 7) ? xcd : (n & 7)) + idx;
   }
 
+  // cells per column of the accumulate form of the 7^3 sweep: patches per wave along x, waves per workgroup along y
+  constexpr int S7_TILE_X = 9, S7_TILE_Y = 4;
+
   enum PatchKind
   {
     PATCH_CELL   = 0, // element-centred, m = p - 1 + 2 n_overlap (matrix_free.h:90)
@@ -112,6 +115,10 @@ namespace asmamd
     const double *s7_wyz[2]; // [k][j] products of the z and y weight factors of the box's cells (pre, post)
     const int *   s7_others; // the cells outside the box (linear index), for the generic kernel
     int           s7_n_others;
+    // accumulate form (fdm_slice7_acc): flag[d][storage index] = 0 where exactly one column (S7_TILE_X x S7_TILE_Y cells) /
+    // z chunk (s7_lz layers) of the box touches the DoF plane and no cell outside the box does; nullptr: not available
+    const unsigned char *s7_flag[3];
+    int                  s7_lz;
     int           small;     // m <= 3: one thread per cell, the patch in registers (kernels_small.hip)
   };
 

@@ -23,11 +23,16 @@ namespace asmamd
     // without tmp: 1 = every DoF has exactly one patch with a non-zero weight (restricted additive Schwarz on
     // element-centred patches, one rank): the patch kernel stores the updated value itself - no zeroing, no atomics,
     // no update passes; constrained DoFs are set by vec_constrained_fused afterwards
+    // 2 = beside fdm_slice7_acc: the listed cells outside the box add f2 * contribution with atomics, constrained DoFs skipped
     int direct = 0;
   };
   bool fdm_generic(const DevGrid &g, const DevFdm &f, const double *src, double *dst, double *tmp, const FdmFused &fu, hipStream_t st);
   // kernels_slice7.hip: the patch solves of the box f.s7_* into tmp[cell][343] (false: not applicable)
   bool fdm_slice7(const DevGrid &g, const DevFdm &f, const double *src, double *tmp, hipStream_t st);
+  // the whole 7^3 sweep without tmp (f.s7_flag set, one rank): dst = the fused update fu of P^-1 src; the box's patch
+  // results are summed in LDS while a workgroup marches along z, the cells outside the box and the DoF planes between
+  // two workgroups' columns are added with atomics (false: not applicable)
+  bool fdm_slice7_acc(const DevGrid &g, const DevFdm &f, const double *src, double *dst, const FdmFused &fu, hipStream_t st);
   // dst += sign * A src (sign = -1 on a dst initialised with b gives the residual b - A src in one pass)
   bool laplace_generic(const DevGrid &g, const DevOp &op, const double *src, double *dst, bool diag, hipStream_t st, double sign = 1.0);
 

@@ -200,7 +200,7 @@ namespace asmamd
       const int  lt     = tid % C::M2;
       const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
       // M = 7 with a slice-per-lane box (kernels_slice7.hip): this kernel takes the other cells, from a compact list
-      const bool listed = M == 7 && STORE && f.s7_on;
+      const bool listed = M == 7 && f.s7_on && (STORE || fu.direct == 2);
       const int  blk    = (int)xcd_block(blockIdx.x, gridDim.x);
       const int  slot   = blk * C::CPB + lc;
       const bool active = (lc < C::CPB) && (slot < (listed ? f.s7_n_others : ncells));
@@ -359,6 +359,14 @@ namespace asmamd
                       const long long o = base + g.store_index(2, K) * g.stride[2];
                       if (!fu.direct)
                         unsafeAtomicAdd(&dst[o], u[k] * w);
+                      else if (fu.direct == 2)
+                        {
+                          // beside fdm_slice7_acc: dst holds the other terms of the update, constrained DoFs their final value
+                          if (fu.mode == PC_PLAIN)
+                            unsafeAtomicAdd(&dst[o], u[k] * w);
+                          else if (!(g.dirichlet(0, I) || g.dirichlet(1, J) || g.dirichlet(2, K)))
+                            unsafeAtomicAdd(&dst[o], fu.f2 * (u[k] * w));
+                        }
                       else if (!(g.dirichlet(0, I) || g.dirichlet(1, J) || g.dirichlet(2, K)))
                         {
                           // (constrained DoFs are left alone: vec_constrained_fused sets them from the unit row and must
@@ -871,6 +879,17 @@ namespace asmamd
   {
     const int ncells = g.nc[0] * g.nc[1] * g.nc[2];
     const int blocks = (ncells + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
+    if (tmp == nullptr && fu.direct == 2)
+      {
+        // the cells outside the slice-per-lane box, added with atomics (fdm_slice7_acc)
+        if constexpr (M == 7)
+          {
+            const int others = (f.s7_n_others + FdmCfg<M>::CPB - 1) / FdmCfg<M>::CPB;
+            if (others > 0)
+              hipLaunchKernelGGL((fdm_generic_kernel<M, false>), dim3(others), dim3(BLOCK), 0, st, g, f, fu, src, dst);
+          }
+        return;
+      }
     if (tmp == nullptr)
       {
         if (fu.direct || !(M <= 3 && f.small && fdm_cell(g, f, src, dst, false, st)))

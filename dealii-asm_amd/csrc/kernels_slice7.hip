@@ -26,8 +26,9 @@ namespace asmamd
     constexpr int H   = 3;  // M / 2
     constexpr int NEV = 4;  // even eigenvectors
     constexpr int E   = M2 + M; // eigen data per instance
-    constexpr int PPW = 9;  // patches per wave
+    constexpr int PPW = S7_TILE_X; // patches per wave
     constexpr int WPB = 4;  // waves per workgroup
+    constexpr int AW  = S7_TILE_Y; // waves per workgroup of the accumulate form
     constexpr int TB7 = 64 * M; // doubles of a wave's transpose buffer
 
     struct UniformMatrix7
@@ -131,28 +132,18 @@ namespace asmamd
       int           npx;          // waves along x
       const double *qx, *qy, *qz; // the region's eigenvector matrices (E doubles each)
       const double *inv;          // [c][b][a] reciprocal eigenvalue sums of the region's instance triple
+      // accumulate form: columns of PPW x WPB cells, z chunks of lz layers; flag[d][storage index] = 0: only one column /
+      // chunk of the box touches the DoF plane in direction d
+      int                  ntx, nty, nzc, lz;
+      const unsigned char *flag[3];
     };
 
+    // gather + solve of one wave's patches on the uniform box; result in layout A: lane = x index `sub`, v[k*7 + j]
     template <bool HAS_PRE, bool HAS_POST>
-    __global__ void __launch_bounds__(WPB * 64, 3)
-    fdm_slice7_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const double *__restrict__ src, double *__restrict__ tmp)
+    __device__ __forceinline__ void
+    solve_uniform(double (&v)[M2], const DevGrid &g, const DevFdm &f, const Slice7Args &sa, const double *__restrict__ src, const int cx,
+                  const int cy, const int cz, const int lane, const int cl, const int sub, double *__restrict__ Tw)
     {
-      __shared__ double S_T[WPB * TB7];
-      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-      const long long gw = xcd_block(blockIdx.x, gridDim.x) * WPB + w; // wave index: (px, cy, cz)
-      const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
-      if (gw >= n_waves)
-        return; // no barrier in this kernel
-      const int px = (int)(gw % sa.npx), cy = sa.lo[1] + (int)((gw / sa.npx) % sa.n[1]), cz = sa.lo[2] + (int)(gw / ((long long)sa.npx * sa.n[1]));
-      int       cl = lane / M;
-      const int sub = lane - cl * M;
-      int       cx  = sa.lo[0] + px * PPW + cl;
-      // lanes without a patch (lane 63, patches beyond the region) run along on the last valid patch and store nothing
-      const bool active = cl < PPW && cx < sa.lo[0] + sa.n[0];
-      if (!active)
-        cx = sa.lo[0] + sa.n[0] - 1;
-      double *Tw = S_T + w * TB7;
-
       const int o0 = f.origin_mul * cx + f.origin_add, o1 = f.origin_mul * cy + f.origin_add, o2 = f.origin_mul * cz + f.origin_add;
       // every DoF of a region patch exists (the region's cells have both neighbours in every direction)
       // Orientation: the 7 lanes of a patch are its x indices, the registers v[k*7 + j] its (z, y) plane - the lanes of a
@@ -164,7 +155,6 @@ namespace asmamd
       for (int jj = 0; jj < M; ++jj)
         yoff[jj] = g.store_index_near(1, o1 + jj) * g.stride[1];
 
-      double v[M2];
       // ---- gather: layout A, lane = x index `sub`, v[k*7 + j]
 #pragma unroll
       for (int k = 0; k < M; ++k)
@@ -209,6 +199,28 @@ namespace asmamd
           for (int e = 0; e < M2; ++e)
             v[e] = (v[e] * wyz[e]) * wx;
         }
+    }
+
+    template <bool HAS_PRE, bool HAS_POST>
+    __global__ void __launch_bounds__(WPB * 64, 3)
+    fdm_slice7_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const double *__restrict__ src, double *__restrict__ tmp)
+    {
+      __shared__ double S_T[WPB * TB7];
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      const long long gw = xcd_block(blockIdx.x, gridDim.x) * WPB + w; // wave index: (px, cy, cz)
+      const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
+      if (gw >= n_waves)
+        return; // no barrier in this kernel
+      const int px = (int)(gw % sa.npx), cy = sa.lo[1] + (int)((gw / sa.npx) % sa.n[1]), cz = sa.lo[2] + (int)(gw / ((long long)sa.npx * sa.n[1]));
+      int       cl = lane / M;
+      const int sub = lane - cl * M;
+      int       cx  = sa.lo[0] + px * PPW + cl;
+      // lanes without a patch (lane 63, patches beyond the region) run along on the last valid patch and store nothing
+      const bool active = cl < PPW && cx < sa.lo[0] + sa.n[0];
+      if (!active)
+        cx = sa.lo[0] + sa.n[0] - 1;
+      double v[M2];
+      solve_uniform<HAS_PRE, HAS_POST>(v, g, f, sa, src, cx, cy, cz, lane, cl, sub, S_T + w * TB7);
       if (active)
         {
           const long long cell = cx + (long long)g.nc[0] * (cy + (long long)g.nc[1] * cz);
@@ -274,32 +286,18 @@ namespace asmamd
         line7_reg<FWD>(v[0 * M + f], v[1 * M + f], v[2 * M + f], v[3 * M + f], v[4 * M + f], v[5 * M + f], v[6 * M + f], Q);
     }
 
+    // gather + solve of one wave's patches with per-cell eigen-decompositions; result in layout A as solve_uniform
     template <bool HAS_PRE, bool HAS_POST>
-    __global__ void __launch_bounds__(WPB * 64, 2)
-    fdm_slice7_cell_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const double *__restrict__ src, double *__restrict__ tmp)
+    __device__ __forceinline__ void
+    solve_percell(double (&v)[M2], const DevGrid &g, const DevFdm &f, const double *__restrict__ src, const int cx, const int cy, const int cz,
+                  const int lane, const int cl, const int sub, double *__restrict__ Tw)
     {
-      __shared__ double S_T[WPB * TB7];
-      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-      const long long gw = xcd_block(blockIdx.x, gridDim.x) * WPB + w; // wave index: (px, cy, cz)
-      const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
-      if (gw >= n_waves)
-        return; // no barrier in this kernel
-      const int px = (int)(gw % sa.npx), cy = sa.lo[1] + (int)((gw / sa.npx) % sa.n[1]), cz = sa.lo[2] + (int)(gw / ((long long)sa.npx * sa.n[1]));
-      int       cl = lane / M;
-      const int sub = lane - cl * M;
-      int       cx  = sa.lo[0] + px * PPW + cl;
-      const bool active = cl < PPW && cx < sa.lo[0] + sa.n[0];
-      if (!active)
-        cx = sa.lo[0] + sa.n[0] - 1;
-      double *Tw = S_T + w * TB7;
-
       const int o0 = f.origin_mul * cx + f.origin_add, o1 = f.origin_mul * cy + f.origin_add, o2 = f.origin_mul * cz + f.origin_add;
       const long long ce = (cx + 1) + (long long)(g.nc[0] + 2) * ((cy + 1) + (long long)(g.nc[1] + 2) * (cz + 1));
       const double *  ex = f.eig + (long long)f.inst[0][ce] * E, *ey = f.eig + (long long)f.inst[1][ce] * E,
                    *ez = f.eig + (long long)f.inst[2][ce] * E;
-      // lanes along x, registers v[k*7 + j] (as in fdm_slice7_kernel)
+      // lanes along x, registers v[k*7 + j] (as in solve_uniform)
       const long long xoff = g.store_index_near(0, o0 + sub);
-      double          v[M2];
 #pragma unroll
       for (int k = 0; k < M; ++k)
         {
@@ -364,6 +362,27 @@ namespace asmamd
                 v[k * M + jj] *= f.w_post[1][(cy + 1) * M + jj] * wzx;
             }
         }
+    }
+
+    template <bool HAS_PRE, bool HAS_POST>
+    __global__ void __launch_bounds__(WPB * 64, 2)
+    fdm_slice7_cell_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const double *__restrict__ src, double *__restrict__ tmp)
+    {
+      __shared__ double S_T[WPB * TB7];
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      const long long gw = xcd_block(blockIdx.x, gridDim.x) * WPB + w; // wave index: (px, cy, cz)
+      const long long n_waves = (long long)sa.npx * sa.n[1] * sa.n[2];
+      if (gw >= n_waves)
+        return; // no barrier in this kernel
+      const int px = (int)(gw % sa.npx), cy = sa.lo[1] + (int)((gw / sa.npx) % sa.n[1]), cz = sa.lo[2] + (int)(gw / ((long long)sa.npx * sa.n[1]));
+      int       cl = lane / M;
+      const int sub = lane - cl * M;
+      int       cx  = sa.lo[0] + px * PPW + cl;
+      const bool active = cl < PPW && cx < sa.lo[0] + sa.n[0];
+      if (!active)
+        cx = sa.lo[0] + sa.n[0] - 1;
+      double v[M2];
+      solve_percell<HAS_PRE, HAS_POST>(v, g, f, src, cx, cy, cz, lane, cl, sub, S_T + w * TB7);
       if (active)
         {
           const long long cell = cx + (long long)g.nc[0] * (cy + (long long)g.nc[1] * cz);
@@ -372,6 +391,202 @@ namespace asmamd
           for (int e = 0; e < M2; ++e)
             out[e * M] = v[e];
         }
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // Owner-computes form of the 7^3 sweep (cell_operation_overlap with its scatter-add, include/matrix_free.h:1066-1162,
+    // read_write_operation.h:3-132) WITHOUT the tmp[cell][343] round trip (43 B/DoF written and read again):
+    //   * a workgroup of WPB waves takes a column of PPW x WPB cells and marches along z over a chunk of sa.lz layers;
+    //     wave w solves the PPW patches of cell row w of the layer, exactly as the kernels above;
+    //   * the patch results are summed in an LDS accumulator (ds_add_f64) of 8 z planes x (4 WPB + 3) rows x (4 PPW + 3)
+    //     DoFs, used as a ring along z: the patches of layer l cover planes 4 l ... 4 l + 6 of the chunk, the first
+    //     four of which no later layer touches; they are written out after the layer and their ring slots zeroed;
+    //   * a DoF that only this workgroup's patches touch (sa.flag[d] = 0 in all three directions) is stored once, with
+    //     the vector update PreconditionChebyshev hands over (FdmFused) applied in the same instruction stream; a DoF
+    //     shared with a neighbouring column / chunk or with the cells outside the box (3 DoF planes per side of a
+    //     column) is added with a global atomic to a value that s7_init_kernel has set to the update's other terms.
+    // HBM traffic: src once per patch row through the caches, dst once; no temporary.
+    // ---------------------------------------------------------------------------------------------------------------
+    constexpr int AY = 4 * AW + 3, AXP = 4 * PPW + 4, RING = 8; // rows, padded row length, planes of the accumulator
+
+    // Writes finished planes of the accumulator.  A thread keeps its (at most EPT) row/column positions for the whole
+    // march; per call it reads and zeroes all its entries, then issues every load of x / x_old, then stores: the
+    // latencies of a layer's loads overlap instead of following each other entry by entry.
+    constexpr int EPT = (AY * AXP + AW * 64 - 1) / (AW * 64); // accumulator entries of a plane per thread
+    struct Emitter
+    {
+      const DevGrid &g;
+      const FdmFused &fu;
+      const Slice7Args &sa;
+      double *       S_A, *dst;
+      double         f2;
+      int            oz, r[EPT];
+      long long      oxy[EPT];
+      int            kind[EPT]; // 0: not part of the column, 1: this workgroup's alone in x and y, 2: shared, 3: shared and constrained
+
+      template <int NP>
+      __device__ __forceinline__ void
+      planes(const int P0) const
+      {
+        double    val[NP][EPT], xv[NP][EPT], xo[NP][EPT];
+        long long o[NP][EPT];
+        bool      own[NP][EPT];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          {
+            const int       P = P0 + pl, sk = g.store_index_near(2, oz + P);
+            double *        plane = S_A + (P & (RING - 1)) * (AY * AXP);
+            const bool      fz = sa.flag[2][sk] != 0;
+            const long long ok = sk * g.stride[2];
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+              {
+                val[pl][i] = 0.;
+                own[pl][i] = kind[i] == 1 && !fz;
+                o[pl][i]   = oxy[i] + ok;
+                if (kind[i])
+                  {
+                    val[pl][i]  = f2 * plane[r[i]];
+                    plane[r[i]] = 0.;
+                  }
+              }
+          }
+        if (fu.mode == PC_STEP1 || fu.mode == PC_UPDATE)
+          {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+              for (int i = 0; i < EPT; ++i)
+                xv[pl][i] = own[pl][i] ? fu.x[o[pl][i]] : 0.;
+          }
+        if (fu.mode == PC_UPDATE)
+          {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+              for (int i = 0; i < EPT; ++i)
+                xo[pl][i] = own[pl][i] ? fu.x_old[o[pl][i]] : 0.;
+          }
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+          for (int i = 0; i < EPT; ++i)
+            {
+              if (own[pl][i])
+                {
+                  double t = val[pl][i];
+                  if (fu.mode == PC_STEP1)
+                    t = fma(fu.f1, xv[pl][i], t);
+                  else if (fu.mode == PC_UPDATE)
+                    t = xv[pl][i] + fu.f1 * (xv[pl][i] - xo[pl][i]) + t;
+                  dst[o[pl][i]] = t;
+                }
+              else if (kind[i])
+                {
+                  // (a box patch never reaches a constrained DoF; the test keeps the contract with s7_init_kernel)
+                  if (fu.mode == PC_PLAIN || !(kind[i] == 3 || g.dirichlet(2, oz + P0 + pl)))
+                    unsafeAtomicAdd(&dst[o[pl][i]], val[pl][i]);
+                }
+            }
+      }
+    };
+
+    template <bool HAS_PRE, bool HAS_POST, bool PERCELL>
+    __global__ void __launch_bounds__(AW * 64, AW <= 4 ? 2 : 1)
+    fdm_slice7_acc_kernel(const DevGrid g, const DevFdm f, const Slice7Args sa, const FdmFused fu, const double *__restrict__ src, double *dst)
+    {
+      extern __shared__ __attribute__((aligned(16))) double s7_lds[];
+      double *S_T = s7_lds, *S_A = s7_lds + AW * TB7;
+      const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+      const long long b  = xcd_block(blockIdx.x, gridDim.x);
+      const int       tx = (int)(b % sa.ntx), ty = (int)((b / sa.ntx) % sa.nty), zc = (int)(b / ((long long)sa.ntx * sa.nty));
+      const int cx0 = sa.lo[0] + tx * PPW, cy0 = sa.lo[1] + ty * AW, z_begin = sa.lo[2] + zc * sa.lz;
+      const int z_end = min(z_begin + sa.lz, sa.lo[2] + sa.n[2]);
+      const int ncx = min(PPW, sa.lo[0] + sa.n[0] - cx0), ncy = min(AW, sa.lo[1] + sa.n[1] - cy0); // cells of this column
+      const int cols = 4 * ncx + 3, rows = 4 * ncy + 3;
+      const int cl = lane / M, sub = lane - cl * M;
+      const bool wave_on = w < ncy, active = wave_on && cl < ncx;
+      const int  cx = cx0 + (cl < ncx ? cl : ncx - 1), cy = cy0 + (wave_on ? w : 0);
+      for (int e = tid; e < RING * AY * AXP; e += AW * 64)
+        S_A[e] = 0.;
+      __syncthreads();
+      // logical coordinates of the accumulator's first column / row / plane
+      const int    ox = f.origin_mul * cx0 + f.origin_add, oy = f.origin_mul * cy0 + f.origin_add, oz = f.origin_mul * z_begin + f.origin_add;
+      const double f2 = fu.mode == PC_PLAIN ? 1. : fu.f2;
+      double *     acc = S_A + (4 * w) * AXP + 4 * cl + sub;
+      Emitter      emit{g, fu, sa, S_A, dst, f2, oz};
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        {
+          const int e = tid + i * (AW * 64), row = e / AXP, col = e - row * AXP;
+          emit.r[i]    = e;
+          emit.kind[i] = 0;
+          emit.oxy[i]  = 0;
+          if (row < rows && col < cols)
+            {
+              const int si = g.store_index_near(0, ox + col), sj = g.store_index_near(1, oy + row);
+              emit.oxy[i]  = si * g.stride[0] + sj * g.stride[1];
+              emit.kind[i] = !(sa.flag[0][si] | sa.flag[1][sj]) ? 1 : ((g.dirichlet(0, ox + col) || g.dirichlet(1, oy + row)) ? 3 : 2);
+            }
+        }
+      for (int cz = z_begin; cz < z_end; ++cz)
+        {
+          const int lay = cz - z_begin;
+          if (wave_on)
+            {
+              double v[M2];
+              if (PERCELL)
+                solve_percell<HAS_PRE, HAS_POST>(v, g, f, src, cx, cy, cz, lane, cl, sub, S_T + w * TB7);
+              else
+                solve_uniform<HAS_PRE, HAS_POST>(v, g, f, sa, src, cx, cy, cz, lane, cl, sub, S_T + w * TB7);
+              if (active)
+                {
+#pragma unroll
+                  for (int k = 0; k < M; ++k)
+                    {
+                      double *plane = acc + ((4 * lay + k) & (RING - 1)) * (AY * AXP);
+#pragma unroll
+                      for (int j = 0; j < M; ++j)
+                        __hip_atomic_fetch_add(plane + j * AXP, v[k * M + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+          __syncthreads();
+          emit.template planes<4>(4 * lay);
+          if (cz == z_end - 1)
+            emit.template planes<3>(4 * lay + 4);
+          __syncthreads();
+        }
+    }
+
+    // the terms of the fused update that do not come from the patches, on every DoF the accumulate kernel (or the generic
+    // kernel, which takes the cells outside the box) adds to with atomics; constrained DoFs get their final value (unit
+    // rows, include/matrix_free_internal.h:247-255) and are skipped by the atomics
+    __global__ void __launch_bounds__(256)
+    s7_init_kernel(const DevGrid g, const FdmFused fu, const unsigned char *__restrict__ f0, const unsigned char *__restrict__ f1,
+                   const unsigned char *__restrict__ f2, const double *__restrict__ src, double *dst)
+    {
+      const int       sx = g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.ext_hi[1] - g.ext_lo[1] + 1;
+      const long long row = blockIdx.x; // (sj, sk)
+      const int       sj = (int)(row % sy), sk = (int)(row / sy);
+      const bool      fyz = f1[sj] | f2[sk];
+      const bool      cyz = g.dirichlet(1, sj + g.ext_lo[1]) || g.dirichlet(2, sk + g.ext_lo[2]);
+      for (int si = threadIdx.x; si < sx; si += blockDim.x)
+        if (fyz | f0[si])
+          {
+            const long long o = si * g.stride[0] + sj * g.stride[1] + sk * g.stride[2];
+            double          t = 0.;
+            if (fu.mode == PC_STEP1)
+              t = fu.f1 * fu.x[o];
+            else if (fu.mode == PC_UPDATE)
+              {
+                const double xv = fu.x[o];
+                t               = xv + fu.f1 * (xv - fu.x_old[o]);
+              }
+            if (fu.mode != PC_PLAIN && (cyz || g.dirichlet(0, si + g.ext_lo[0])))
+              t += fu.f2 * src[o];
+            dst[o] = t;
+          }
     }
   } // namespace
 
@@ -415,5 +630,55 @@ namespace asmamd
     else
       hipLaunchKernelGGL((fdm_slice7_kernel<false, false>), dim3(blocks), dim3(WPB * 64), 0, st, g, f, sa, src, tmp);
     return true;
+  }
+
+  bool
+  fdm_slice7_acc(const DevGrid &g, const DevFdm &f, const double *src, double *dst, const FdmFused &fu_in, hipStream_t st)
+  {
+    if (!f.s7_on || f.m != M || f.origin_mul != 4 || f.s7_flag[0] == nullptr || f.s7_lz < 1)
+      return false;
+    FdmFused fu = fu_in;
+    fu.direct   = 2;
+    Slice7Args sa;
+    for (int d = 0; d < 3; ++d)
+      {
+        sa.lo[d]   = f.s7_lo[d];
+        sa.n[d]    = f.s7_hi[d] - f.s7_lo[d];
+        sa.flag[d] = f.s7_flag[d];
+      }
+    sa.npx = (sa.n[0] + PPW - 1) / PPW;
+    sa.qx  = f.eig + (long long)(f.s7_on == 1 ? f.s7_inst[0] : 0) * E;
+    sa.qy  = f.eig + (long long)(f.s7_on == 1 ? f.s7_inst[1] : 0) * E;
+    sa.qz  = f.eig + (long long)(f.s7_on == 1 ? f.s7_inst[2] : 0) * E;
+    sa.inv = f.s7_inv;
+    sa.ntx = sa.npx;
+    sa.nty = (sa.n[1] + AW - 1) / AW;
+    sa.lz  = f.s7_lz;
+    sa.nzc = (sa.n[2] + sa.lz - 1) / sa.lz;
+    const int sy = g.ext_hi[1] - g.ext_lo[1] + 1, sz = g.ext_hi[2] - g.ext_lo[2] + 1;
+    hipLaunchKernelGGL(s7_init_kernel, dim3((unsigned)(sy * sz)), dim3(256), 0, st, g, fu, sa.flag[0], sa.flag[1], sa.flag[2], src, dst);
+    if (!fdm_generic(g, f, src, dst, nullptr, fu, st)) // the cells outside the box
+      return false;
+    const unsigned blocks = (unsigned)(sa.ntx * sa.nty * sa.nzc);
+    const size_t lds = sizeof(double) * (AW * TB7 + RING * AY * AXP);
+    const auto   launch = [&](auto kernel) {
+      if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+      hipLaunchKernelGGL(kernel, dim3(blocks), dim3(AW * 64), lds, st, g, f, sa, fu, src, dst);
+      return true;
+    };
+    bool ok = false;
+#define ASM_S7_ACC(PRE, POST) \
+  ok = f.s7_on == 2 ? launch(fdm_slice7_acc_kernel<PRE, POST, true>) : launch(fdm_slice7_acc_kernel<PRE, POST, false>)
+    if (f.has_pre && f.has_post)
+      ASM_S7_ACC(true, true);
+    else if (f.has_pre)
+      ASM_S7_ACC(true, false);
+    else if (f.has_post)
+      ASM_S7_ACC(false, true);
+    else
+      ASM_S7_ACC(false, false);
+#undef ASM_S7_ACC
+    return ok;
   }
 } // namespace asmamd

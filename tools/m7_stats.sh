@@ -14,6 +14,6 @@ import csv, glob
 for f in glob.glob('gpurun_out/kt7/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Name']
-        if 'fdm_' in n or 'laplace_cart_tiled_kernel<1>' in n or 'laplace_generic' in n:
+        if "fdm_" in n or "s7_init" in n or 'laplace_cart_tiled_kernel<1>' in n or 'laplace_generic' in n:
             print('  %-44s calls %4s avg %8.1f us' % (n.split('(anonymous namespace)::')[1][:44], r['Calls'], float(r['AverageNs']) / 1e3))
 PY

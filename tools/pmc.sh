@@ -19,7 +19,7 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob('gpurun_out/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if not any(t in k for t in ('laplace_cart_tiled', 'fdm_tiled', 'laplace_generic', 'fdm_generic', 'fdm_gather', 'fdm_slice7')):
+        if not any(t in k for t in ('laplace_cart_tiled', 'fdm_tiled', 'laplace_generic', 'fdm_generic', 'fdm_gather', 'fdm_slice7', 's7_init')):
             continue
         # kernel name with its template arguments, without the parameter list (the context's tuning launches of
         # other kernel variants stay separate rows)
