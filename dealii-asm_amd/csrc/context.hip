@@ -127,6 +127,18 @@ struct asm_ctx
         }                                                                                          \
     }                                                                                              \
   while (0)
+// a box copy the launcher refused (kernels.h: vec_box / vec_boxes): unknown mode, missing buffer, box outside the extent
+#define BOX_TRY_CTX(c_, expr)                                                                      \
+  do                                                                                               \
+    {                                                                                              \
+      if (!(expr))                                                                                 \
+        {                                                                                          \
+          (c_)->error = "box copy refused (mode / buffer / extent): " #expr;                       \
+          return ASM_ERR_INVALID_VALUE;                                                            \
+        }                                                                                          \
+    }                                                                                              \
+  while (0)
+#define BOX_TRY(expr) BOX_TRY_CTX(ctx, expr)
 #define HIP_TRY(expr)                                                                              \
   do                                                                                               \
     {                                                                                              \
@@ -280,7 +292,7 @@ namespace
     if (!add && ctx->n_dmsg > 0)
       {
         // one round: pack all boxes, one grouped send/recv with every neighbour, unpack all boxes
-        vec_boxes(g, 0, v, ctx->dbuf[0], ctx->dsend, ctx->stream);
+        BOX_TRY(vec_boxes(g, 0, v, ctx->dbuf[0], ctx->dsend, ctx->stream));
         NCCL_TRY(ncclGroupStart());
         for (int i = 0; i < ctx->n_dmsg; ++i)
           if (ctx->dmsg[i].send_count > 0)
@@ -291,7 +303,7 @@ namespace
             NCCL_TRY(ncclRecv(ctx->dbuf[1] + ctx->dmsg[i].recv_offset, ctx->dmsg[i].recv_count, ncclDouble, ctx->dmsg[i].peer,
                               ctx->comm, ctx->stream));
         NCCL_TRY(ncclGroupEnd());
-        vec_boxes(g, 1, v, ctx->dbuf[1], ctx->drecv, ctx->stream);
+        BOX_TRY(vec_boxes(g, 1, v, ctx->dbuf[1], ctx->drecv, ctx->stream));
         return ASM_OK;
       }
     static const bool dimension_ordered = std::getenv("ASM_COMPRESS_BY_DIMENSION") != nullptr; // experiments: the three-round form
@@ -301,7 +313,7 @@ namespace
         // to the rank that owns it (face, edge and corner neighbours alike) and is added there; then the
         // ghost boxes are zeroed (zero_out_ghost_values).  Sends in array order, receives in reverse order:
         // the pairing argument of the update applies unchanged.
-        vec_boxes(g, 0, v, ctx->dbuf[1], ctx->drecv, ctx->stream);
+        BOX_TRY(vec_boxes(g, 0, v, ctx->dbuf[1], ctx->drecv, ctx->stream));
         NCCL_TRY(ncclGroupStart());
         for (int i = 0; i < ctx->n_dmsg; ++i)
           if (ctx->dmsg[i].recv_count > 0)
@@ -312,8 +324,8 @@ namespace
             NCCL_TRY(ncclRecv(ctx->dbuf[0] + ctx->dmsg[i].send_offset, ctx->dmsg[i].send_count, ncclDouble, ctx->dmsg[i].peer,
                               ctx->comm, ctx->stream));
         NCCL_TRY(ncclGroupEnd());
-        vec_boxes(g, 2, v, ctx->dbuf[0], ctx->dsend, ctx->stream);
-        vec_boxes(g, 3, v, nullptr, ctx->drecv, ctx->stream);
+        BOX_TRY(vec_boxes(g, 2, v, ctx->dbuf[0], ctx->dsend, ctx->stream));
+        BOX_TRY(vec_boxes(g, 3, v, nullptr, ctx->drecv, ctx->stream));
         return ASM_OK;
       }
     asm_exchange_step steps[3];
@@ -332,7 +344,7 @@ namespace
                 return ASM_ERR_INVALID_VALUE;
               }
             if (cnt_send[sd] > 0)
-              vec_box(g, 0, v, ctx->hbuf[sd], st.send_lo[sd], st.send_size[sd], ctx->stream);
+              BOX_TRY(vec_box(g, 0, v, ctx->hbuf[sd], st.send_lo[sd], st.send_size[sd], ctx->stream));
           }
         NCCL_TRY(ncclGroupStart());
         // sends: low then high; receives: high then low, so that with two ranks in a
@@ -347,11 +359,11 @@ namespace
         NCCL_TRY(ncclGroupEnd());
         for (int sd = 0; sd < 2; ++sd)
           if (cnt_recv[sd] > 0)
-            vec_box(g, add ? 2 : 1, v, ctx->hbuf[2 + sd], st.recv_lo[sd], st.recv_size[sd], ctx->stream);
+            BOX_TRY(vec_box(g, add ? 2 : 1, v, ctx->hbuf[2 + sd], st.recv_lo[sd], st.recv_size[sd], ctx->stream));
         if (add) // zero_out_ghost_values
           for (int sd = 0; sd < 2; ++sd)
             if (cnt_send[sd] > 0)
-              vec_box(g, 3, v, nullptr, st.send_lo[sd], st.send_size[sd], ctx->stream);
+              BOX_TRY(vec_box(g, 3, v, nullptr, st.send_lo[sd], st.send_size[sd], ctx->stream));
       }
     return ASM_OK;
   }
@@ -466,7 +478,7 @@ namespace
     if (add)
       {
         // compress(add): the single-round update run backwards (see exchange): ghost boxes -> their owners, added there
-        vec_boxes(ctx->g, 0, v, ctx->dbuf[1], ctx->drecv, st);
+        BOX_TRY(vec_boxes(ctx->g, 0, v, ctx->dbuf[1], ctx->drecv, st));
         HIP_TRY(hipStreamSynchronize(st));
         lg.barrier(); // every rank has packed its ghost boxes
         for (int i = 0; i < ctx->n_dmsg; ++i)
@@ -490,11 +502,11 @@ namespace
           }
         HIP_TRY(hipStreamSynchronize(st));
         lg.barrier(); // every rank has read its neighbours' buffers
-        vec_boxes(ctx->g, 2, v, ctx->dbuf[0], ctx->dsend, st);
-        vec_boxes(ctx->g, 3, v, nullptr, ctx->drecv, st);
+        BOX_TRY(vec_boxes(ctx->g, 2, v, ctx->dbuf[0], ctx->dsend, st));
+        BOX_TRY(vec_boxes(ctx->g, 3, v, nullptr, ctx->drecv, st));
         return ASM_OK;
       }
-    vec_boxes(ctx->g, 0, v, ctx->dbuf[0], ctx->dsend, st);
+    BOX_TRY(vec_boxes(ctx->g, 0, v, ctx->dbuf[0], ctx->dsend, st));
     HIP_TRY(hipStreamSynchronize(st));
     lg.barrier(); // every rank has packed
     for (int i = 0; i < ctx->n_dmsg; ++i)
@@ -518,7 +530,7 @@ namespace
       }
     HIP_TRY(hipStreamSynchronize(st));
     lg.barrier(); // every rank has read its neighbours' send buffers
-    vec_boxes(ctx->g, 1, v, ctx->dbuf[1], ctx->drecv, st);
+    BOX_TRY(vec_boxes(ctx->g, 1, v, ctx->dbuf[1], ctx->drecv, st));
     return ASM_OK;
   }
 
@@ -537,7 +549,7 @@ namespace
         ctx->exchange_pending = true;
         return ASM_OK;
       }
-    vec_boxes(ctx->g, 0, v, ctx->dbuf[0], ctx->dsend, ctx->comm_stream);
+    BOX_TRY(vec_boxes(ctx->g, 0, v, ctx->dbuf[0], ctx->dsend, ctx->comm_stream));
     NCCL_TRY(ncclGroupStart());
     for (int i = 0; i < ctx->n_dmsg; ++i)
       if (ctx->dmsg[i].send_count > 0)
@@ -548,7 +560,7 @@ namespace
         NCCL_TRY(ncclRecv(ctx->dbuf[1] + ctx->dmsg[i].recv_offset, ctx->dmsg[i].recv_count, ncclDouble, ctx->dmsg[i].peer, ctx->comm,
                           ctx->comm_stream));
     NCCL_TRY(ncclGroupEnd());
-    vec_boxes(ctx->g, 1, v, ctx->dbuf[1], ctx->drecv, ctx->comm_stream);
+    BOX_TRY(vec_boxes(ctx->g, 1, v, ctx->dbuf[1], ctx->drecv, ctx->comm_stream));
     HIP_TRY(hipEventRecord(ctx->ev_exchanged, ctx->comm_stream));
     ctx->exchanged_vec    = v;
     ctx->exchange_pending = true;
@@ -1134,6 +1146,36 @@ asm_params_set(asm_params *p, const char *key, const char *value)
         p->polynomial_type = ASM_POLY_FOURTH_KIND;
       else
         return fail("Polynomial type");
+      return ASM_OK;
+    }
+  // Keys of the reference's preconditioner block that choose between implementations of the same mathematical
+  // operation there (precondition.templates.h:195-211, 341, 388, 534): this library has one implementation of each, so
+  // every value the reference accepts is taken and changes nothing - a driver can forward the reference's JSON block
+  // verbatim.  Values the reference itself would reject are rejected.
+  const auto is_bool = [&]() { return v == "true" || v == "false" || v == "1" || v == "0"; };
+  if (k == "reuse partitioner") // one partitioner (box layout) serves the operator and the patches
+    return is_bool() ? ASM_OK : fail("Reuse partitioner");
+  if (k == "overlap pre post") // the ghost exchange overlaps the sweep whenever a block has interfaces (ASM_NO_OVERLAP)
+    return is_bool() ? ASM_OK : fail("Overlap pre post");
+  if (k == "weight sequence") // where the weights are multiplied in: matrix_free.h:84-94, 717-779; the same numbers
+    return (v == "global" || v == "compressed" || v == "dg") ? ASM_OK : fail("Weight sequence");
+  if (k == "optimize") // how much of the Chebyshev iteration is fused into the sweeps (0-3): always everything
+    {
+      int32_t o = 0;
+      return (to_int(o) && o >= 0 && o <= 3) ? ASM_OK : fail("Optimize");
+    }
+  if (k == "sub mesh approximation")
+    {
+      // cells per direction of the sub-mesh the patch matrices are assembled from: the reference's default (dim = 3,
+      // the full neighbourhood) is what setup.h implements
+      int32_t n = 0;
+      if (!to_int(n) || n < 1 || n > 3)
+        return fail("Sub mesh approximation");
+      if (n != 3)
+        {
+          g_create_error = "sub mesh approximation <" + v + "> is not implemented (only the reference's default, 3)";
+          return ASM_ERR_NOT_SUPPORTED;
+        }
       return ASM_OK;
     }
   g_create_error = "unknown option key <" + k + ">";
@@ -1755,7 +1797,7 @@ asm_internal_zero_ghosts(asm_ctx *ctx, double *v)
 {
   const DeviceScope device_scope(ctx);
   if (multi_rank(ctx) && ctx->n_dmsg > 0)
-    vec_boxes(ctx->g, 3, v, nullptr, ctx->drecv, ctx->stream);
+    BOX_TRY(vec_boxes(ctx->g, 3, v, nullptr, ctx->drecv, ctx->stream));
   return launch_status(ctx, "zero ghosts");
 }
 
@@ -1862,7 +1904,7 @@ asm_vector_import(asm_ctx *ctx, double *dev, const double *host_owned)
   HIP_TRY(hipMalloc((void **)&buf, ctx->s.n_owned * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(buf, host_owned, ctx->s.n_owned * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemsetAsync(dev, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
-  vec_box(g, 1, dev, buf, lo, size, ctx->stream);
+  BOX_TRY(vec_box(g, 1, dev, buf, lo, size, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipFree(buf));
   return ASM_OK;
@@ -1876,7 +1918,7 @@ asm_vector_export(asm_ctx *ctx, double *host_owned, const double *dev)
   const int      lo[3] = {0, 0, 0}, size[3] = {g.own_hi[0] + 1, g.own_hi[1] + 1, g.own_hi[2] + 1};
   double *       buf   = nullptr;
   HIP_TRY(hipMalloc((void **)&buf, ctx->s.n_owned * sizeof(double)));
-  vec_box(g, 0, const_cast<double *>(dev), buf, lo, size, ctx->stream);
+  BOX_TRY(vec_box(g, 0, const_cast<double *>(dev), buf, lo, size, ctx->stream));
   HIP_TRY(hipMemcpyAsync(host_owned, buf, ctx->s.n_owned * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipFree(buf));
@@ -2411,7 +2453,7 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
       // single-round compress(add): the ghost box rank r holds for offset o is added to the box its peer sends
       // towards -o in the update
       for (int r = 0; r < n; ++r)
-        vec_boxes(ctxs[r]->g, 0, vecs[r], ctxs[r]->dbuf[1], ctxs[r]->drecv, ctxs[r]->stream);
+        BOX_TRY_CTX(ctxs[r], vec_boxes(ctxs[r]->g, 0, vecs[r], ctxs[r]->dbuf[1], ctxs[r]->drecv, ctxs[r]->stream));
       HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
       for (int r = 0; r < n; ++r)
         for (int i = 0; i < ctxs[r]->n_dmsg; ++i)
@@ -2435,8 +2477,8 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
           }
       for (int r = 0; r < n; ++r)
         {
-          vec_boxes(ctxs[r]->g, 2, vecs[r], ctxs[r]->dbuf[0], ctxs[r]->dsend, ctxs[r]->stream);
-          vec_boxes(ctxs[r]->g, 3, vecs[r], nullptr, ctxs[r]->drecv, ctxs[r]->stream);
+          BOX_TRY_CTX(ctxs[r], vec_boxes(ctxs[r]->g, 2, vecs[r], ctxs[r]->dbuf[0], ctxs[r]->dsend, ctxs[r]->stream));
+          BOX_TRY_CTX(ctxs[r], vec_boxes(ctxs[r]->g, 3, vecs[r], nullptr, ctxs[r]->drecv, ctxs[r]->stream));
         }
       HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
       return ASM_OK;
@@ -2445,7 +2487,7 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
     {
       // single-round plan: what rank r receives from offset o is what its peer sends towards -o
       for (int r = 0; r < n; ++r)
-        vec_boxes(ctxs[r]->g, 0, vecs[r], ctxs[r]->dbuf[0], ctxs[r]->dsend, ctxs[r]->stream);
+        BOX_TRY_CTX(ctxs[r], vec_boxes(ctxs[r]->g, 0, vecs[r], ctxs[r]->dbuf[0], ctxs[r]->dsend, ctxs[r]->stream));
       HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
       for (int r = 0; r < n; ++r)
         for (int i = 0; i < ctxs[r]->n_dmsg; ++i)
@@ -2468,7 +2510,7 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
                                            m.recv_count * sizeof(double), hipMemcpyDeviceToDevice));
           }
       for (int r = 0; r < n; ++r)
-        vec_boxes(ctxs[r]->g, 1, vecs[r], ctxs[r]->dbuf[1], ctxs[r]->drecv, ctxs[r]->stream);
+        BOX_TRY_CTX(ctxs[r], vec_boxes(ctxs[r]->g, 1, vecs[r], ctxs[r]->dbuf[1], ctxs[r]->drecv, ctxs[r]->stream));
       HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
       return ASM_OK;
     }
@@ -2482,7 +2524,7 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
       for (int r = 0; r < n; ++r)
         for (int sd = 0; sd < 2; ++sd)
           if (steps[r][i].peer[sd] >= 0 && count(steps[r][i].send_size[sd]) > 0)
-            vec_box(ctxs[r]->g, 0, vecs[r], ctxs[r]->hbuf[sd], steps[r][i].send_lo[sd], steps[r][i].send_size[sd], ctxs[r]->stream);
+            BOX_TRY_CTX(ctxs[r], vec_box(ctxs[r]->g, 0, vecs[r], ctxs[r]->hbuf[sd], steps[r][i].send_lo[sd], steps[r][i].send_size[sd], ctxs[r]->stream));
       HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
       for (int r = 0; r < n; ++r)
         for (int sd = 0; sd < 2; ++sd)
@@ -2506,11 +2548,11 @@ asm_debug_exchange_all(asm_ctx **ctxs, double **vecs, int n, int add)
           const asm_exchange_step &st = steps[r][i];
           for (int sd = 0; sd < 2; ++sd)
             if (st.peer[sd] >= 0 && count(st.recv_size[sd]) > 0)
-              vec_box(ctxs[r]->g, add ? 2 : 1, vecs[r], ctxs[r]->hbuf[2 + sd], st.recv_lo[sd], st.recv_size[sd], ctxs[r]->stream);
+              BOX_TRY_CTX(ctxs[r], vec_box(ctxs[r]->g, add ? 2 : 1, vecs[r], ctxs[r]->hbuf[2 + sd], st.recv_lo[sd], st.recv_size[sd], ctxs[r]->stream));
           if (add)
             for (int sd = 0; sd < 2; ++sd)
               if (st.peer[sd] >= 0 && count(st.send_size[sd]) > 0)
-                vec_box(ctxs[r]->g, 3, vecs[r], nullptr, st.send_lo[sd], st.send_size[sd], ctxs[r]->stream);
+                BOX_TRY_CTX(ctxs[r], vec_box(ctxs[r]->g, 3, vecs[r], nullptr, st.send_lo[sd], st.send_size[sd], ctxs[r]->stream));
         }
       HIP_TRY_CTX(ctxs[0], hipDeviceSynchronize());
     }

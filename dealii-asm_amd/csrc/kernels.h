@@ -7,6 +7,10 @@
 
 #include <vector>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#  error "the kernels are written for gfx950 (wave64): their shuffle offsets, per-wave partial sums and lane maps assume 64 lanes"
+#endif
+
 namespace asmamd
 {
   // ---- generic sweeps (kernels_generic.hip): dst must be zeroed by the caller,
@@ -119,8 +123,9 @@ namespace asmamd
   // the guide's 6.29), i.e. the achievable HBM rate next to the 8 TB/s peak
   void vec_stream_copy(void *dst, const void *src, long long n_vec16, hipStream_t st);
   // box copy between a packed buffer and a vector (halo exchange, import/export)
-  // mode 0: buf <- vec ; 1: vec <- buf ; 2: vec += buf ; 3: vec <- 0
-  void vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st);
+  // mode 0: buf <- vec ; 1: vec <- buf ; 2: vec += buf ; 3: vec <- 0 (buf unused)
+  // false (nothing launched): unknown mode, missing operand or a box outside the stored extent
+  bool vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st);
   // the same for up to 26 boxes in one launch: box b is copied to / from buf + offset[b]
   struct BoxList
   {
@@ -128,5 +133,5 @@ namespace asmamd
     int       lo[26][3], size[26][3];
     long long offset[26];
   };
-  void vec_boxes(const DevGrid &g, int mode, double *vec, double *buf, const BoxList &boxes, hipStream_t st);
+  bool vec_boxes(const DevGrid &g, int mode, double *vec, double *buf, const BoxList &boxes, hipStream_t st);
 } // namespace asmamd

@@ -447,24 +447,50 @@ namespace asmamd
       return;
     hipLaunchKernelGGL(constrained_fused_kernel, dim3(64, 6), dim3(VB), 0, st, g, fu, dst, src);
   }
-  void
+  namespace
+  {
+    // a box copy the kernel can execute: a known mode, the operands it dereferences, a box inside the stored extent
+    bool
+    box_valid(const DevGrid &g, const int mode, const double *vec, const double *buf, const int lo[3], const int size[3])
+    {
+      if (mode < 0 || mode > 3 || vec == nullptr || (mode != 3 && buf == nullptr))
+        return false;
+      for (int d = 0; d < 3; ++d)
+        {
+          const int n_store = g.wrap[d] ? g.nc[d] * g.p : g.ext_hi[d] - g.ext_lo[d] + 1;
+          if (size[d] < 0 || size[d] > n_store || (!g.wrap[d] && (lo[d] < g.ext_lo[d] || lo[d] + size[d] - 1 > g.ext_hi[d])))
+            return false;
+        }
+      return true;
+    }
+  } // namespace
+  bool
   vec_box(const DevGrid &g, int mode, double *vec, double *buf, const int lo[3], const int size[3], hipStream_t st)
   {
+    if (!box_valid(g, mode, vec, buf, lo, size))
+      return false;
     const long long n = (long long)size[0] * size[1] * size[2];
     if (n <= 0)
-      return;
+      return true;
     hipLaunchKernelGGL(box_kernel, dim3(grid_for(n, 4)), dim3(VB), 0, st, g, mode, vec, buf, lo[0], lo[1], lo[2], size[0],
                        size[1], size[2]);
+    return true;
   }
-  void
+  bool
   vec_boxes(const DevGrid &g, int mode, double *vec, double *buf, const BoxList &boxes, hipStream_t st)
   {
-    if (boxes.n <= 0)
-      return;
+    if (boxes.n < 0 || boxes.n > 26)
+      return false;
+    for (int b = 0; b < boxes.n; ++b)
+      if (!box_valid(g, mode, vec, buf, boxes.lo[b], boxes.size[b]) || boxes.offset[b] < 0)
+        return false;
+    if (boxes.n == 0)
+      return true;
     long long largest = 1;
     for (int b = 0; b < boxes.n; ++b)
       largest = std::max(largest, (long long)boxes.size[b][0] * boxes.size[b][1] * boxes.size[b][2]);
     hipLaunchKernelGGL(boxes_kernel, dim3(grid_for(largest, 4), boxes.n), dim3(VB), 0, st, g, mode, vec, buf, boxes);
+    return true;
   }
   namespace
   {

@@ -211,6 +211,9 @@ void asm_params_default(asm_params *p);
  *   "ev algorithm" = lanczos|power iteration, "polynomial type" = 1st kind|4th kind
  *                                              (create_chebyshev_preconditioner, :108-152, 481-573)
  *   "fe degree" (the top-level "degree" of the experiment files: polynomial degree of FE_Q)
+ *   "weight sequence" = global|compressed|dg, "reuse partitioner", "overlap pre post" = true|false, "optimize" = 0..3:
+ *     implementation choices of the reference that leave the numbers unchanged (:195-211, 341, 388, 534): validated and
+ *     accepted, no effect here; "sub mesh approximation": only the default 3 (other values: ASM_ERR_NOT_SUPPORTED)
  * Unknown keys or values return ASM_ERR_INVALID_VALUE, where the reference throws
  * (precondition.templates.h:26, 79-81, 130-133, 148-152). */
 int asm_params_set(asm_params *p, const char *key, const char *value);

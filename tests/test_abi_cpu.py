@@ -117,6 +117,18 @@ def test_params_set_accepts_reference_keys_and_rejects_unknown(pkg):
                        ("degree", "three")]:
         assert lib.asm_params_set(C.byref(p), key.encode(), value.encode()) != 0, (key, value)
         assert "not known" in lib.asm_last_error(None).decode() or "unknown option key" in lib.asm_last_error(None).decode()
+    # the reference's implementation-choice keys (precondition.templates.h:195-211, 341, 388, 534): every value the
+    # reference takes is accepted and leaves the parameters unchanged, so its JSON block can be forwarded verbatim
+    before = bytes(p)
+    for key, value in [("weight sequence", "global"), ("weight sequence", "compressed"), ("weight sequence", "dg"),
+                       ("reuse partitioner", "true"), ("reuse partitioner", "false"), ("overlap pre post", "false"),
+                       ("optimize", "0"), ("optimize", "3"), ("sub mesh approximation", "3")]:
+        assert lib.asm_params_set(C.byref(p), key.encode(), value.encode()) == 0, (key, value)
+    assert bytes(p) == before
+    for key, value in [("weight sequence", "local"), ("reuse partitioner", "maybe"), ("optimize", "4"), ("sub mesh approximation", "0")]:
+        assert lib.asm_params_set(C.byref(p), key.encode(), value.encode()) == 1, (key, value)
+    assert lib.asm_params_set(C.byref(p), b"sub mesh approximation", b"1") == 2
+    assert "not implemented" in lib.asm_last_error(None).decode()
     # the Chebyshev parameter checks of the layout setup
     q = pkg.make_params(cheb_degree=0)
     with pytest.raises(ValueError):
