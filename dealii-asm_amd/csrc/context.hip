@@ -21,6 +21,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <map>
 
 #ifdef ASM_STAMP
 namespace asmamd
@@ -953,6 +954,8 @@ namespace
   // quantisation, rounds of workgroups): measured once per context, two launches per candidate on the
   // scratch vectors.  All candidates sum the contributions to a DoF in the same order: the choice
   // does not change results.  ASM_TILED_ROWS=0|9|10|11 fixes it (experiments).
+  std::mutex                         g_tune_mutex;
+  std::map<std::array<int, 14>, int> g_tune_cache;
   int
   tune_tiled_laplace(asm_ctx *ctx)
   {
@@ -964,6 +967,28 @@ namespace
         ctx->laplace_rows = (r >= 9 && r <= 11) ? r : 0;
         return ASM_OK;
       }
+    // one measurement per device, block shape and boundary kinds in a process: contexts of the same shape (the ranks'
+    // blocks in a loopback group, repeated creation) take the same variant, and a creation beside other work on the GPU
+    // does not measure again (ASM_TILED_ROWS still overrides)
+    std::array<int, 14> key;
+    key[0] = ctx->device;
+    for (int d = 0; d < 3; ++d)
+      {
+        key[1 + d]  = ctx->g.nc[d];
+        key[4 + d]  = ctx->g.wrap[d];
+        key[7 + d]  = ctx->g.dir_lo[d] * 2 + ctx->g.dir_hi[d];
+        key[10 + d] = ctx->g.ext_hi[d] - ctx->g.ext_lo[d];
+      }
+    key[13] = ctx->op.cartesian;
+    {
+      std::lock_guard<std::mutex> lock(g_tune_mutex);
+      const auto                  hit = g_tune_cache.find(key);
+      if (hit != g_tune_cache.end())
+        {
+          ctx->laplace_rows = hit->second;
+          return ASM_OK;
+        }
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -1013,6 +1038,10 @@ namespace
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ctx->laplace_rows = pick;
+    {
+      std::lock_guard<std::mutex> lock(g_tune_mutex);
+      g_tune_cache[key] = pick;
+    }
     HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     return ASM_OK;
   }

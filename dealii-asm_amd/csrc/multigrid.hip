@@ -20,6 +20,10 @@
 
 #include <hip/hip_runtime.h>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#  error "written for gfx950 (wave64): the reductions of dense_apply_kernel assume 64 lanes"
+#endif
+
 #include <algorithm>
 #include <array>
 #include <cmath>
