@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstdlib>
 
@@ -1552,19 +1553,31 @@ namespace asmamd
       // the last owned plane nc*p of a non-wrapped direction is produced by the tile
       // that holds cell nc-1, no extra tile needed
       const int tiles = tl.ntx * tl.nty;
-      // One workgroup per CU at a time.  Workgroups run in rounds of n_cu; a chunk of zlen layers
-      // costs zlen + 1 layer times (halo layer) plus about half a layer of start-up: take the
-      // number of chunks with the smallest  rounds x (zlen + 1.5).
+      // One workgroup per CU at a time; a chunk of zlen layers costs zlen + 1 layer times (halo layer) plus about half a
+      // layer of start-up.  The workgroups are handed out as compute units fall free and live up to 1.35 times as long
+      // at Dirichlet faces as inside (profiles/r03_workgroup_trace.txt), so the launch takes between work / n_cu and
+      // whole rounds of the longest workgroup, plus a tail of about half a workgroup: the chunk count with the smallest
+      //   (ceil(N / n_cu) + N / n_cu) / 2 x L + tail x L,   N = tiles x chunks, L = zlen + 1.5
+      // Round 2's model, rounds x L alone, took ONE chunk of 96 layers for 128 x 128 x 96 cells (228 workgroups on 256
+      // compute units in a single round, no balancing at all): P 0.98 ms where four to twelve chunks give 0.76-0.80
+      // (profiles/r03_zchunks_north_star.txt); at 80^3 both models take 8 chunks.
       if (n_cu <= 0)
         n_cu = 256;
+      // (a block without Dirichlet faces has workgroups of one length: no tail term; the periodic 128 x 64 x 64 box runs
+      //  its 240 workgroups of two chunks in one round, 0.50 ms per step against 0.53 with eight chunks)
+      static const double tail_env = std::getenv("ASM_TILED_TAIL") ? std::atof(std::getenv("ASM_TILED_TAIL")) : 0.5; // experiments
+      bool                uneven   = false;
+      for (int d = 0; d < 3; ++d)
+        uneven = uneven || g.dir_lo[d] || g.dir_hi[d];
+      const double tail = uneven ? tail_env : 0.;
       int    best      = 1;
       double best_cost = 1e300;
       for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
         {
           const int    zlen   = (g.nc[2] + nzc - 1) / nzc;
           const int    chunks = (g.nc[2] + zlen - 1) / zlen;
-          const int    rounds = (tiles * chunks + n_cu - 1) / n_cu;
-          const double cost   = rounds * (zlen + 1.5);
+          const double N      = (double)tiles * chunks, L = zlen + 1.5;
+          const double cost   = 0.5 * (std::ceil(N / n_cu) + N / n_cu) * L + tail * L;
           if (cost < best_cost - 1e-9)
             {
               best_cost = cost;
