@@ -206,6 +206,7 @@ EXPORTED_SYMBOLS = [
     "asm_mg_restrict",
     "asm_mg_vmult",
     "asm_mg_coarse_failures",
+    "asm_mg_graph_replays",
     "asm_mg_comm_init",
     "asm_mg_level_distributed",
     "asm_solver_params_default",
@@ -291,6 +292,7 @@ def load_library():
     lib.asm_mg_level_distributed.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.asm_mg_debug_after_loopback.argtypes = [C.c_void_p]
     lib.asm_mg_coarse_failures.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.asm_mg_graph_replays.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.asm_solver_params_default.argtypes = [C.POINTER(AsmSolverParams)]
     lib.asm_solver_params_default.restype = None
     lib.asm_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(AsmSolverParams), C.c_void_p, C.c_void_p, C.POINTER(AsmSolverResult)]
@@ -709,6 +711,12 @@ class Multigrid:
         d = C.c_int32()
         self._check(self.lib.asm_mg_level_distributed(self.handle, level, C.byref(d)))
         return bool(d.value)
+
+    def graph_replays(self):
+        """(level, replays) of the hipGraph of the small levels' legs; level -1: no graph"""
+        level, n = C.c_int32(), C.c_int64()
+        self._check(self.lib.asm_mg_graph_replays(self.handle, C.byref(level), C.byref(n)))
+        return level.value, n.value
 
     def comm_init(self, unique_id: bytes):
         """asm_mg_comm_init: one RCCL communicator for all block-decomposed levels (collective)"""

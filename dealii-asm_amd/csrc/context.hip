@@ -1820,6 +1820,27 @@ asm_internal_exchange(asm_ctx *ctx, double *v, int add)
   return exchange(ctx, v, add != 0);
 }
 
+// hipGraph capture of the V-cycle's coarse legs: the level contexts issue their work on `stream` while it is being
+// captured; returns the previous stream
+void *
+asm_internal_swap_stream(asm_ctx *ctx, void *stream)
+{
+  void *old   = (void *)ctx->stream;
+  ctx->stream = (hipStream_t)stream;
+  return old;
+}
+
+// what a captured Chebyshev sweep of this context has baked into its kernel arguments: a graph is replayed only while
+// these values stand
+void
+asm_internal_cheb_state(const asm_ctx *ctx, double out[4])
+{
+  out[0] = ctx->ev_set ? 1. : 0.;
+  out[1] = ctx->theta;
+  out[2] = ctx->delta;
+  out[3] = ctx->s.prm.cheb_degree + 16. * ctx->s.prm.polynomial_type;
+}
+
 // zero_out_ghost_values
 int
 asm_internal_zero_ghosts(asm_ctx *ctx, double *v)

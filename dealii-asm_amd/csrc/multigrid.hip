@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -268,6 +269,8 @@ extern "C" int asm_internal_exchange(asm_ctx *ctx, double *v, int add);
 extern "C" int asm_internal_zero_ghosts(asm_ctx *ctx, double *v);
 extern "C" int asm_internal_allreduce(asm_ctx *ctx, double *v, long long n);
 extern "C" int asm_internal_comm_share(asm_ctx *dst, asm_ctx *src);
+extern "C" void *asm_internal_swap_stream(asm_ctx *ctx, void *stream);
+extern "C" void asm_internal_cheb_state(const asm_ctx *ctx, double out[4]);
 
 struct asm_mg
 {
@@ -284,6 +287,14 @@ struct asm_mg
   int         intermediate_level = 0;
   double *    rc_r = nullptr, *rc_d = nullptr; // "n coarse cycles" > 1: residual and correction on that level
   long long   coarse_not_converged = 0;        // coarse CG solves that hit their iteration limit
+  // hipGraph of the legs at and below graph_level (small levels: some sixty launches of 5-10 us each, bound by the launch
+  // rate): captured on the second V-cycle, replayed while the levels' Chebyshev parameters stand.  -1: none
+  int                 graph_level = -1;
+  int                 graph_state = 0; // 0: next V-cycle runs eagerly (lazy kernel set-up), 1: capture / replay, -1: off
+  hipStream_t         graph_stream = nullptr;
+  hipGraphExec_t      graph_exec   = nullptr;
+  std::vector<double> graph_signature;
+  long long           graph_replays = 0;
   std::string error;
 };
 
@@ -965,6 +976,87 @@ namespace
   // `top`: the level is entered as a level of the multigrid above, i.e. - on the intermediate level - as the coarse-grid
   // problem of the upper multigrid: "n coarse cycles" Richardson steps preconditioned by the lower one
   // (SolverRelaxation under IterationNumberControl, include/multigrid.h:346-365)
+  int v_cycle(asm_mg *mg, const int level, double *x, double *b, const bool top);
+
+  // The V-cycle from `level` down (on the hierarchy's own level vectors) as one hipGraph launch.  The capture runs the
+  // ordinary code with the level contexts' work directed at a capture stream; nothing is executed by it, the graph is
+  // launched on the hierarchy's stream afterwards.  Any failure to capture switches graphs off and runs eagerly.
+  int
+  coarse_legs_graph(asm_mg *mg, const int level)
+  {
+    if (mg->graph_state == 0)
+      {
+        mg->graph_state = 1; // the first V-cycle: eager (kernel attributes, tuned variants are settled by it)
+        return v_cycle(mg, level, nullptr, nullptr, true);
+      }
+    std::vector<double> sig;
+    for (int l = 0; l <= level; ++l)
+      {
+        double st[4];
+        asm_internal_cheb_state(mg->levels[l].ctx, st);
+        sig.insert(sig.end(), st, st + 4);
+      }
+    if (mg->graph_exec != nullptr && sig == mg->graph_signature)
+      {
+        if (hipGraphLaunch(mg->graph_exec, mg->stream) != hipSuccess)
+          {
+            (void)hipGetLastError();
+            mg->graph_state = -1;
+            return v_cycle(mg, level, nullptr, nullptr, true);
+          }
+        ++mg->graph_replays;
+        return ASM_OK;
+      }
+    if (mg->graph_exec != nullptr)
+      {
+        (void)hipGraphExecDestroy(mg->graph_exec);
+        mg->graph_exec = nullptr;
+      }
+    const auto give_up = [&]() {
+      (void)hipGetLastError();
+      mg->graph_state = -1;
+      return v_cycle(mg, level, nullptr, nullptr, true);
+    };
+    if (mg->graph_stream == nullptr && hipStreamCreateWithFlags(&mg->graph_stream, hipStreamNonBlocking) != hipSuccess)
+      return give_up();
+    std::vector<void *> saved(level + 1);
+    for (int l = 0; l <= level; ++l)
+      saved[l] = asm_internal_swap_stream(mg->levels[l].ctx, (void *)mg->graph_stream);
+    const hipStream_t mg_stream = mg->stream;
+    mg->stream                  = mg->graph_stream;
+    hipGraph_t graph            = nullptr;
+    int        err              = ASM_OK;
+    const bool began            = hipStreamBeginCapture(mg->graph_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+    if (began)
+      {
+        err = v_cycle(mg, level, nullptr, nullptr, true);
+        if (hipStreamEndCapture(mg->graph_stream, &graph) != hipSuccess)
+          graph = nullptr;
+      }
+    for (int l = 0; l <= level; ++l)
+      (void)asm_internal_swap_stream(mg->levels[l].ctx, saved[l]);
+    mg->stream = mg_stream;
+    if (!began || err != ASM_OK || graph == nullptr)
+      {
+        if (graph)
+          (void)hipGraphDestroy(graph);
+        mg->error.clear();
+        return give_up();
+      }
+    const hipError_t inst = hipGraphInstantiate(&mg->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (inst != hipSuccess)
+      {
+        mg->graph_exec = nullptr;
+        return give_up();
+      }
+    mg->graph_signature = sig;
+    if (hipGraphLaunch(mg->graph_exec, mg->stream) != hipSuccess)
+      return give_up();
+    ++mg->graph_replays;
+    return ASM_OK;
+  }
+
   int
   v_cycle(asm_mg *mg, const int level, double *x = nullptr, double *b = nullptr, const bool top = true)
   {
@@ -1014,7 +1106,10 @@ namespace
     MG_CTX(mg, lv.ctx, asm_cheb_vmult(lv.ctx, x, b));                                    // pre-smoothing, x_0 = 0
     MG_CTX(mg, lv.ctx, asm_op_vmult_fused(lv.ctx, ASM_FUSED_RESIDUAL, lv.r, x, b));      // r = b - A x
     MG_TRY(asm_mg_restrict(mg, level, lc.b, lv.r));
-    MG_TRY(v_cycle(mg, level - 1));
+    if (level - 1 == mg->graph_level && mg->graph_state >= 0)
+      MG_TRY(coarse_legs_graph(mg, level - 1));
+    else
+      MG_TRY(v_cycle(mg, level - 1));
     MG_TRY(asm_mg_prolongate_add(mg, level, x, lc.x));
     if (!mg->mp.one_sided_v_cycle)
       MG_CTX(mg, lv.ctx, asm_cheb_step(lv.ctx, x, b));                                   // post-smoothing
@@ -1094,6 +1189,10 @@ asm_mg_destroy(asm_mg *mg)
         (void)asm_vector_free(mg->levels[mg->intermediate_level].ctx, v);
   if (mg->coarse_inverse)
     (void)hipFree(mg->coarse_inverse);
+  if (mg->graph_exec)
+    (void)hipGraphExecDestroy(mg->graph_exec);
+  if (mg->graph_stream)
+    (void)hipStreamDestroy(mg->graph_stream);
   for (Level &lv : mg->levels)
     {
       if (lv.ctx)
@@ -1275,11 +1374,38 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
       if (const int err = build_coarse_inverse(mg, error))
         return fail(err, error);
     }
+  // hipGraph of the small levels' legs (one rank; the coarse CG synchronises with the host and cannot be captured):
+  // everything from the highest level of at most 2^20 stored DoFs down, if that is below the finest level.
+  // OFF unless ASM_MG_GRAPH is set: measured, the replay is no faster than the plain launches on this stack (V-cycle 1.130
+  // against 1.137 ms at 48^3 cells, 2.72 against 2.86 ms at 80^3: the kernels of a graph still follow each other at
+  // 5-10 us; profiles/r03_mg_graph.txt)
+  if (fine->world_size == 1 && mp.coarse_solver != ASM_MG_COARSE_CG && std::getenv("ASM_MG_GRAPH") != nullptr)
+    {
+      long long limit = 1ll << 20;
+      if (const char *e = std::getenv("ASM_MG_GRAPH_DOFS"))
+        limit = std::atoll(e);
+      for (int l = L - 2; l >= 1; --l)
+        if (mg->levels[l].layout.n_alloc <= limit)
+          {
+            mg->graph_level = l;
+            break;
+          }
+    }
   // (a multi-rank hierarchy estimates them once it has its communicator: asm_mg_comm_init)
   if (mp.estimate_eigenvalues && fine->world_size == 1)
     if (const int err = estimate_level_eigenvalues(mg))
       return fail(err, mg->error);
   *out = holder.release();
+  return ASM_OK;
+}
+
+int
+asm_mg_graph_replays(const asm_mg *mg, int32_t *level, int64_t *replays)
+{
+  if (!mg || !level || !replays)
+    return ASM_ERR_INVALID_VALUE;
+  *level   = mg->graph_state >= 0 ? mg->graph_level : -1;
+  *replays = mg->graph_replays;
   return ASM_OK;
 }
 

@@ -440,6 +440,13 @@ int asm_mg_vmult(asm_mg *mg, double *dst, const double *src);
  * coarse_rel_tolerance since the hierarchy was created: the V-cycles went on with an inexact coarse correction (the
  * reference's AMG V-cycle, include/precondition.templates.h:592-613, is inexact by construction and reports nothing) */
 int asm_mg_coarse_failures(const asm_mg *mg, int64_t *count);
+/* hipGraph of the V-cycle's small levels (one rank, coarse solver other than ASM_MG_COARSE_CG; only if the environment
+ * variable ASM_MG_GRAPH is set when the hierarchy is created - measured no faster than the plain launches on ROCm 7.2, so
+ * off by default): the legs from *level down - the highest level of at most 2^20 stored DoFs below the finest - are captured
+ * on the second V-cycle and replayed as one graph launch while the levels' Chebyshev parameters stand; *level = -1: no graph
+ * (not requested, not applicable, or the capture was refused and the hierarchy went back to plain launches); *replays = graph
+ * launches so far.  Not in the reference (CPU); results are bit for bit those of the plain launches. */
+int asm_mg_graph_replays(const asm_mg *mg, int32_t *level, int64_t *replays);
 
 /* solve(), element_centered_preconditioners_01.cc:108-263: SolverCG / SolverGMRES under ReductionControl */
 enum asm_solver_type

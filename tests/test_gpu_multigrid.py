@@ -393,3 +393,42 @@ def test_nested_hierarchies(pkg, n_coarse_cycles, keep_duplicate):
         assert rel(xv.get(), x_ref) < 1e-7
         bv.free()
         xv.free()
+
+
+@pytest.mark.parametrize("coarse,mg_type,n_coarse_cycles", [("smoother", "ph", 1), ("direct", "ph", 2), ("direct", "h", 1)])
+def test_graph_of_small_levels(pkg, monkeypatch, coarse, mg_type, n_coarse_cycles):
+    """hipGraph of the V-cycle's small levels (asm_mg_graph_replays): the first V-cycle runs eagerly, the second is
+    captured, later ones replay - every one bit for bit the V-cycle of a hierarchy without graphs (the default; ASM_MG_GRAPH
+    switches them on), also
+    after a level's Chebyshev parameters change (the graph is captured again)"""
+    nc, p = (8, 8, 4), 4
+    prm = fine_params(pkg, nc, p, "dirichlet", "cartesian", weighting="post", cheb_degree=2)
+    kw = dict(mg_type=mg_type, coarse=coarse, estimate_eigenvalues=False, n_coarse_cycles=n_coarse_cycles)
+    monkeypatch.delenv("ASM_MG_GRAPH", raising=False)
+    plain = pkg.Multigrid(prm, **kw)
+    monkeypatch.setenv("ASM_MG_GRAPH", "1")
+    with plain, pkg.Multigrid(prm, **kw) as mg:
+        assert plain.graph_replays() == (-1, 0)
+        level, replays = mg.graph_replays()
+        assert 1 <= level < mg.n_levels - 1 and replays == 0
+        for h in (plain, mg):
+            for l, c in enumerate(h.levels):
+                c.set_eigenvalue(1.3 + 0.1 * l)
+        rng = np.random.default_rng(4)
+        vecs = [(h.fine.vector(), h.fine.vector()) for h in (plain, mg)]
+        n = vecs[0][0].get().size
+        for it in range(6):
+            if it == 4:  # other parameters on a captured level: the next V-cycle captures again
+                for h in (plain, mg):
+                    h.levels[1].set_eigenvalue(2.0)
+            b = rng.uniform(-1, 1, n)
+            out = []
+            for h, (xv, bv) in zip((plain, mg), vecs):
+                bv.set(b)
+                h.vmult(xv, bv)
+                out.append(xv.get())
+            assert np.array_equal(out[0], out[1]), it
+        assert mg.graph_replays() == (level, 5)  # every V-cycle but the first
+        for xv, bv in vecs:
+            xv.free()
+            bv.free()
