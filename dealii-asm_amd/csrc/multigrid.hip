@@ -113,25 +113,48 @@ namespace
   }
 
   // the z direction: one grid row (blockIdx.y) per output plane, so that the plane's table entries (start, count,
-  // weights) are block-uniform and come through scalar loads, and the loop has a uniform trip count
+  // weights) are block-uniform and come through scalar loads, and the loop has a uniform trip count.  A thread takes
+  // PU outputs of the plane (a quarter of the plane apart) and issues their loads together: with one output per thread
+  // a thread is a single round trip to memory and the passes ran at 2-3.7 TB/s (profiles/r03_transfer_passes.txt)
+  constexpr int PU = 4;
   template <bool ADD>
   __global__ void __launch_bounds__(256)
   transfer_pass_z_kernel(const PassArgs a, double *__restrict__ out, const double *__restrict__ in)
   {
-    const unsigned e2 = blockIdx.x * 256u + threadIdx.x, s0 = (unsigned)a.out.size[0];
-    if (e2 >= s0 * (unsigned)a.out.size[1])
-      return;
-    const unsigned  cj = e2 / s0;
-    const int       ci = (int)(e2 - cj * s0), ck = (int)blockIdx.y;
-    const long long o  = box_offset(a.out, ci, (int)cj, ck);
-    const int       cnt = a.count[ck];
-    const double *  w   = a.val + (long long)ck * a.val_stride;
-    const double *  row = in + box_offset(a.in, ci, (int)cj, a.start[ck]);
-    const long long st  = a.in.stride[2];
-    double          sum = 0.;
+    const unsigned  s0 = (unsigned)a.out.size[0], n2 = s0 * (unsigned)a.out.size[1], span = gridDim.x * 256u;
+    const int       ck = (int)blockIdx.y, cnt = a.count[ck];
+    const double *  w  = a.val + (long long)ck * a.val_stride;
+    const long long st = a.in.stride[2];
+    const double *  row[PU];
+    long long       o[PU];
+    double          sum[PU], prev[PU];
+    bool            on[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+      {
+        const unsigned e2 = blockIdx.x * 256u + threadIdx.x + u * span;
+        on[u]             = e2 < n2;
+        const unsigned ee = on[u] ? e2 : 0u, cj = ee / s0;
+        const int      ci = (int)(ee - cj * s0);
+        o[u]              = box_offset(a.out, ci, (int)cj, ck);
+        row[u]            = in + box_offset(a.in, ci, (int)cj, a.start[ck]);
+        sum[u]            = 0.;
+        prev[u]           = (ADD && on[u]) ? out[o[u]] : 0.;
+      }
     for (int k = 0; k < cnt; ++k)
-      sum = fma(w[k], row[k * st], sum);
-    out[o] = ADD ? out[o] + sum : sum;
+      {
+        double v[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          v[u] = row[u][k * st];
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          sum[u] = fma(w[k], v[u], sum[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+      if (on[u])
+        out[o[u]] = ADD ? prev[u] + sum[u] : sum[u];
   }
 
   // the y direction in the same way: one grid row per output ROW index j, the threads of a block run over the (x, z) pairs
@@ -139,20 +162,40 @@ namespace
   __global__ void __launch_bounds__(256)
   transfer_pass_y_kernel(const PassArgs a, double *__restrict__ out, const double *__restrict__ in)
   {
-    const unsigned e2 = blockIdx.x * 256u + threadIdx.x, s0 = (unsigned)a.out.size[0];
-    if (e2 >= s0 * (unsigned)a.out.size[2])
-      return;
-    const unsigned  ck = e2 / s0;
-    const int       ci = (int)(e2 - ck * s0), cj = (int)blockIdx.y;
-    const long long o  = box_offset(a.out, ci, cj, (int)ck);
-    const int       cnt = a.count[cj];
-    const double *  w   = a.val + (long long)cj * a.val_stride;
-    const double *  row = in + box_offset(a.in, ci, a.start[cj], (int)ck);
-    const long long st  = a.in.stride[1];
-    double          sum = 0.;
+    const unsigned  s0 = (unsigned)a.out.size[0], n2 = s0 * (unsigned)a.out.size[2], span = gridDim.x * 256u;
+    const int       cj = (int)blockIdx.y, cnt = a.count[cj];
+    const double *  w  = a.val + (long long)cj * a.val_stride;
+    const long long st = a.in.stride[1];
+    const double *  row[PU];
+    long long       o[PU];
+    double          sum[PU], prev[PU];
+    bool            on[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+      {
+        const unsigned e2 = blockIdx.x * 256u + threadIdx.x + u * span;
+        on[u]             = e2 < n2;
+        const unsigned ee = on[u] ? e2 : 0u, ck = ee / s0;
+        const int      ci = (int)(ee - ck * s0);
+        o[u]              = box_offset(a.out, ci, cj, (int)ck);
+        row[u]            = in + box_offset(a.in, ci, a.start[cj], (int)ck);
+        sum[u]            = 0.;
+        prev[u]           = (ADD && on[u]) ? out[o[u]] : 0.;
+      }
     for (int k = 0; k < cnt; ++k)
-      sum = fma(w[k], row[k * st], sum);
-    out[o] = ADD ? out[o] + sum : sum;
+      {
+        double v[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          v[u] = row[u][k * st];
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          sum[u] = fma(w[k], v[u], sum[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+      if (on[u])
+        out[o[u]] = ADD ? prev[u] + sum[u] : sum[u];
   }
 
   // dst_fine += P src_coarse: one thread per fine DoF
@@ -589,13 +632,13 @@ namespace
     if (a.dir == 2 && a.out.size[2] <= 65535)
       {
         const long long plane = (long long)a.out.size[0] * a.out.size[1];
-        hipLaunchKernelGGL((transfer_pass_z_kernel<ADD>), dim3((unsigned)((plane + 255) / 256), a.out.size[2]), dim3(256), 0, mg->stream, a, out, in);
+        hipLaunchKernelGGL((transfer_pass_z_kernel<ADD>), dim3((unsigned)((plane + 256 * PU - 1) / (256 * PU)), a.out.size[2]), dim3(256), 0, mg->stream, a, out, in);
         return;
       }
     if (a.dir == 1 && a.out.size[1] <= 65535)
       {
         const long long xz = (long long)a.out.size[0] * a.out.size[2];
-        hipLaunchKernelGGL((transfer_pass_y_kernel<ADD>), dim3((unsigned)((xz + 255) / 256), a.out.size[1]), dim3(256), 0, mg->stream, a, out, in);
+        hipLaunchKernelGGL((transfer_pass_y_kernel<ADD>), dim3((unsigned)((xz + 256 * PU - 1) / (256 * PU)), a.out.size[1]), dim3(256), 0, mg->stream, a, out, in);
         return;
       }
     hipLaunchKernelGGL((transfer_pass_kernel<ADD>), dim3(launch_blocks(n)), dim3(256), 0, mg->stream, a, out, in);

@@ -326,6 +326,22 @@ namespace asmamd
     {
       check(asm_mg_restrict(handle_.get(), (int32_t)level, dst_coarse_zeroed.data(), src_fine.data()));
     }
+    // several ranks: ONE communicator for all block-decomposed levels (collective; id = the bytes of asm_comm_unique_id,
+    // broadcast by the launcher), then the levels' eigenvalue estimates; include/multigrid.h:289-346
+    void comm_init(const char id[128]) { check(asm_mg_comm_init(handle_.get(), id)); }
+    bool level_is_distributed(const unsigned int l) const
+    {
+      int32_t d = 0;
+      check(asm_mg_level_distributed(handle_.get(), (int32_t)l, &d));
+      return d != 0;
+    }
+    // coarse-grid CG solves that stopped at their iteration limit since creation
+    long long coarse_failures() const
+    {
+      int64_t n = 0;
+      check(asm_mg_coarse_failures(handle_.get(), &n));
+      return n;
+    }
     void check(const int err) const
     {
       if (err)

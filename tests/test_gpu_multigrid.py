@@ -93,20 +93,32 @@ def test_transfer_parity(pkg, nc, p, bc, mg_type, p_sequence):
                 v.free()
 
 
-def test_transfer_forms_agree(pkg, monkeypatch):
-    """the single-kernel and the direction-by-direction form of the transfers give the same result (rounding apart)"""
-    prm = fine_params(pkg, (20, 16, 12), 4, ["dirichlet", "neumann", "dirichlet"])
+@pytest.mark.parametrize(
+    "nc,p,mg_type,bc",
+    [
+        ((20, 16, 12), 4, "ph", ["dirichlet", "neumann", "dirichlet"]),  # p = 4 -> 2 on the same cells
+        ((40, 32, 24), 2, "h", ["dirichlet", "dirichlet", "neumann"]),   # h-coarsening at p = 2
+        ((8, 8, 6), 7, "p", "dirichlet"),                                # p = 7 -> 3: widest table rows
+        ((66, 34, 66), 1, "h", "dirichlet"),                             # ragged tiles (67 = 64 + 3 DoFs per row)
+    ],
+)
+def test_transfer_forms_agree(pkg, monkeypatch, nc, p, mg_type, bc):
+    """the direction-by-direction form (default on levels of >= 2^17 DoFs) and the single-kernel form
+    (ASM_MG_DIRECT_TRANSFER) of the transfers give the same result (rounding apart)"""
+    prm = fine_params(pkg, nc, p, bc)
     rng = np.random.default_rng(11)
     out = []
-    for direct in (False, True):
-        if direct:
+    for form in ("pass", "direct"):
+        monkeypatch.delenv("ASM_MG_DIRECT_TRANSFER", raising=False)
+        if form == "direct":
             monkeypatch.setenv("ASM_MG_DIRECT_TRANSFER", "1")
-        with pkg.Multigrid(prm, mg_type="ph", estimate_eigenvalues=False) as mg:
+        with pkg.Multigrid(prm, mg_type=mg_type, estimate_eigenvalues=False) as mg:
             l = mg.n_levels - 1
             cf, cc = mg.levels[l], mg.levels[l - 1]
+            assert cf.n_dofs >= 1 << 17
             if not out:
                 xc, xf = rng.uniform(-1, 1, cc.n_dofs), rng.uniform(-1, 1, cf.n_dofs)
-            vc, vf, wc = cc.vector(xc), cf.vector(xf), cc.vector()
+            vc, vf, wc = cc.vector(xc), cf.vector(xf), cc.vector(np.full(cc.n_dofs, 7.0))
             mg.restrict(l, wc, vf)
             mg.prolongate_add(l, vf, vc)
             out.append((vf.get(), wc.get()))
