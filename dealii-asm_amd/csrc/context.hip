@@ -657,7 +657,11 @@ namespace
       ctx->exchanged_vec = nullptr;
     // one rank: the residual is accumulated straight into a copy of b (no zeroing pass, no separate b - A x pass)
     const bool fused_residual = mode == OP_RESIDUAL && !multi_rank(ctx);
-    if (fused_residual)
+    // (small levels are bound by the number of launches: the copy and the Dirichlet planes in one)
+    const bool init_kernel = fused_residual && ctx->s.n_alloc < (1ll << 22) && dst != b && dst != src;
+    if (init_kernel)
+      vec_residual_init(ctx->g, dst, b, src, ctx->stream);
+    else if (fused_residual)
       HIP_TRY(hipMemcpyAsync(dst, b, ctx->s.n_alloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     else
       HIP_TRY(hipMemsetAsync(dst, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
@@ -676,7 +680,8 @@ namespace
       {
         if (!fused_residual)
           vec_residual(dst, b, ctx->s.n_alloc, ctx->stream);
-        vec_constrained(ctx->g, 2, dst, src, b, ctx->stream); // r_c = b_c - x_c
+        if (!init_kernel)
+          vec_constrained(ctx->g, 2, dst, src, b, ctx->stream); // r_c = b_c - x_c
       }
     return ASM_OK;
   }

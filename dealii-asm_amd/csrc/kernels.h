@@ -116,6 +116,9 @@ namespace asmamd
   void vec_add_scalar_owned(const DevGrid &g, double *v, double a, hipStream_t st);
   // Dirichlet planes: mode 0: dst = 0 ; 1: dst = src ; 2: dst = b - x
   void vec_constrained(const DevGrid &g, int mode, double *dst, const double *src, const double *b, hipStream_t st);
+  // dst = b, on Dirichlet planes b - x (levels of fewer than 2^22 stored DoFs: one launch where a copy and vec_constrained
+  // would be two; every stored entry, the padding of the rows is left alone)
+  void vec_residual_init(const DevGrid &g, double *dst, const double *b, const double *x, hipStream_t st);
   // Dirichlet planes: dst = the fused update of FdmFused applied to the unit row, i.e. with P^-1 src replaced by src (0 for PC_PLAIN)
   void vec_constrained_fused(const DevGrid &g, const FdmFused &fu, double *dst, const double *src, hipStream_t st);
   // measurement aid: dst = src for n 16-byte vectors, one 16 KB tile per workgroup, four non-temporal 16-byte loads in

@@ -437,6 +437,33 @@ namespace asmamd
       return;
     hipLaunchKernelGGL(constrained_kernel, dim3(64, 6), dim3(VB), 0, st, g, mode, dst, src, b);
   }
+  namespace
+  {
+    // dst = b, on Dirichlet planes b - x: what a residual sweep that adds -A x to dst starts from (one launch instead of a
+    // copy and a pass over the Dirichlet planes; the sweeps neither read nor write constrained rows)
+    __global__ void __launch_bounds__(VB)
+    residual_init_kernel(const DevGrid g, double *__restrict__ dst, const double *__restrict__ b, const double *__restrict__ x)
+    {
+      const unsigned sx = g.wrap[0] ? g.nc[0] * g.p : g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.wrap[1] ? g.nc[1] * g.p : g.ext_hi[1] - g.ext_lo[1] + 1,
+                     sz = g.wrap[2] ? g.nc[2] * g.p : g.ext_hi[2] - g.ext_lo[2] + 1;
+      const unsigned n = sx * sy * sz;
+      for (unsigned e = blockIdx.x * VB + threadIdx.x; e < n; e += gridDim.x * VB)
+        {
+          const unsigned k = e / (sx * sy), r = e - k * (sx * sy), j = r / sx, i = r - j * sx;
+          const long long o = i * g.stride[0] + j * g.stride[1] + k * g.stride[2];
+          const bool      c = g.dirichlet(0, (int)i + (g.wrap[0] ? 0 : g.ext_lo[0])) || g.dirichlet(1, (int)j + (g.wrap[1] ? 0 : g.ext_lo[1])) ||
+                         g.dirichlet(2, (int)k + (g.wrap[2] ? 0 : g.ext_lo[2]));
+          dst[o] = c ? b[o] - x[o] : b[o];
+        }
+    }
+  } // namespace
+  void
+  vec_residual_init(const DevGrid &g, double *dst, const double *b, const double *x, hipStream_t st)
+  {
+    const long long sx = g.wrap[0] ? g.nc[0] * g.p : g.ext_hi[0] - g.ext_lo[0] + 1, sy = g.wrap[1] ? g.nc[1] * g.p : g.ext_hi[1] - g.ext_lo[1] + 1,
+                    sz = g.wrap[2] ? g.nc[2] * g.p : g.ext_hi[2] - g.ext_lo[2] + 1;
+    hipLaunchKernelGGL(residual_init_kernel, dim3(grid_for(sx * sy * sz, 4)), dim3(VB), 0, st, g, dst, b, x);
+  }
   void
   vec_constrained_fused(const DevGrid &g, const FdmFused &fu, double *dst, const double *src, hipStream_t st)
   {
