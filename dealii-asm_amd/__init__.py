@@ -28,7 +28,7 @@ POLYNOMIAL = {"1st kind": 0, "4th kind": 1}
 FUSED = {"none": 0, "residual": 1, "cheb_first": 2, "relax": 3, "cheb_next": 4}
 MG_TYPE = {"h": 0, "p": 1, "hp": 2, "ph": 3}
 MG_P_SEQUENCE = {"bisect": 0, "decrease by one": 1, "go to one": 2}
-MG_COARSE = {"smoother": 0, "cg": 1, "direct": 2}
+MG_COARSE = {"smoother": 0, "cg": 1, "direct": 2, "auto": 3}
 SOLVER = {"CG": 0, "GMRES": 1}
 SYSTEM_PRECONDITIONER = {"Identity": 0, "inner": 1, "Chebyshev": 2, "Multigrid": 3}
 

@@ -1185,7 +1185,7 @@ asm_mg_params_default(asm_mg_params *p)
   p->mg_type               = ASM_MG_H;      // "mg type", default "h"
   p->p_sequence            = ASM_MG_BISECT; // "mg p sequence", default "bisect"
   p->one_sided_v_cycle     = 0;
-  p->coarse_solver         = ASM_MG_COARSE_CG;
+  p->coarse_solver         = ASM_MG_COARSE_AUTO;
   p->coarse_rel_tolerance  = 1e-3;
   p->coarse_max_iterations = 200;
   p->estimate_eigenvalues  = 1;
@@ -1265,7 +1265,7 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
       g_mg_create_error = "multigrid: rank / world_size out of range";
       return ASM_ERR_INVALID_VALUE;
     }
-  if (mp.coarse_solver < ASM_MG_COARSE_SMOOTHER || mp.coarse_solver > ASM_MG_COARSE_DIRECT)
+  if (mp.coarse_solver < ASM_MG_COARSE_SMOOTHER || mp.coarse_solver > ASM_MG_COARSE_AUTO)
     {
       g_mg_create_error = "unknown coarse-grid solver";
       return ASM_ERR_INVALID_VALUE;
@@ -1303,6 +1303,15 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
     return code;
   };
   const std::vector<LevelSpec> specs = level_sequence(*fine, mp);
+  if (mp.coarse_solver == ASM_MG_COARSE_AUTO)
+    {
+      // the dense inverse where level 0 is small enough for it (a linear V-cycle, no host synchronisation inside), else CG
+      long long n0 = 1;
+      for (int d = 0; d < 3; ++d)
+        n0 *= (long long)specs[0].nc[d] * specs[0].p + 1;
+      mp.coarse_solver     = n0 <= MAX_COARSE_DIRECT ? ASM_MG_COARSE_DIRECT : ASM_MG_COARSE_CG;
+      mg->mp.coarse_solver = mp.coarse_solver;
+    }
   mg->levels.resize(specs.size());
   for (size_t l = 0; l < specs.size(); ++l)
     if (specs[l].p == 1)

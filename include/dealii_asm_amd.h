@@ -380,8 +380,10 @@ enum asm_mg_coarse
 {
   ASM_MG_COARSE_SMOOTHER = 0, /* the level-0 Chebyshev smoother's vmult (tests/.../small fixtures) */
   ASM_MG_COARSE_CG       = 1, /* Jacobi-preconditioned CG to a relative tolerance (in place of AMG) */
-  ASM_MG_COARSE_DIRECT   = 2  /* dense inverse of the level operator, built at creation (levels of <= 2048 DoFs): one
+  ASM_MG_COARSE_DIRECT   = 2, /* dense inverse of the level operator, built at creation (levels of <= 2048 DoFs): one
                                * kernel per coarse solve and a linear V-cycle, also in place of AMG */
+  ASM_MG_COARSE_AUTO     = 3  /* default: DIRECT where the coarsest level has at most 2048 DoFs, CG otherwise (a CG coarse solve
+                               * makes the V-cycle a non-linear preconditioner and synchronises with the host every iteration) */
 };
 
 typedef struct asm_mg_params
@@ -445,7 +447,7 @@ int asm_mg_coarse_failures(const asm_mg *mg, int64_t *count);
  * off by default): the legs from *level down - the highest level of at most 2^20 stored DoFs below the finest - are captured
  * on the second V-cycle and replayed as one graph launch while the levels' Chebyshev parameters stand; *level = -1: no graph
  * (not requested, not applicable, or the capture was refused and the hierarchy went back to plain launches); *replays = graph
- * launches so far.  Not in the reference (CPU); results are bit for bit those of the plain launches. */
+ * launches so far.  Not in the reference (CPU); results are those of the plain launches (to the summation order of the low-order sweeps' atomics). */
 int asm_mg_graph_replays(const asm_mg *mg, int32_t *level, int64_t *replays);
 
 /* solve(), element_centered_preconditioners_01.cc:108-263: SolverCG / SolverGMRES under ReductionControl */

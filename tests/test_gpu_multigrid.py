@@ -410,7 +410,7 @@ def test_nested_hierarchies(pkg, n_coarse_cycles, keep_duplicate):
 @pytest.mark.parametrize("coarse,mg_type,n_coarse_cycles", [("smoother", "ph", 1), ("direct", "ph", 2), ("direct", "h", 1)])
 def test_graph_of_small_levels(pkg, monkeypatch, coarse, mg_type, n_coarse_cycles):
     """hipGraph of the V-cycle's small levels (asm_mg_graph_replays): the first V-cycle runs eagerly, the second is
-    captured, later ones replay - every one bit for bit the V-cycle of a hierarchy without graphs (the default; ASM_MG_GRAPH
+    captured, later ones replay - every one the V-cycle of a hierarchy without graphs to rounding (the default; ASM_MG_GRAPH
     switches them on), also
     after a level's Chebyshev parameters change (the graph is captured again)"""
     nc, p = (8, 8, 4), 4
@@ -439,7 +439,7 @@ def test_graph_of_small_levels(pkg, monkeypatch, coarse, mg_type, n_coarse_cycle
                 bv.set(b)
                 h.vmult(xv, bv)
                 out.append(xv.get())
-            assert np.array_equal(out[0], out[1]), it
+            assert rel(out[0], out[1]) < 1e-13, it  # (the low-order sweeps scatter with atomics: summation order, not bit for bit)
         assert mg.graph_replays() == (level, 5)  # every V-cycle but the first
         for xv, bv in vecs:
             xv.free()
