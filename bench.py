@@ -81,6 +81,10 @@ def cpu_baseline(args, pkg, cells):
         import asm_oracle_cpu
 
         threads = max(1, granted if args.cpu_threads <= 0 else min(usable, args.cpu_threads))
+        # fewer threads than hardware threads: one per physical core, spread over the host's core complexes
+        cpus = asm_oracle_cpu.spread_cpus(threads) if (threads < usable and os.environ.get("ASM_BENCH_NO_PIN") is None) else None
+        if cpus:
+            os.environ["ASM_ORACLE_CPUS"] = ",".join(str(c) for c in cpus)
         nc = tuple(cells)  # the mesh of the GPU measurement itself
         lib = asm_oracle_cpu.native_library()  # built here, on the host it runs on, with -march=native
         native = "native" in os.path.basename(lib)
@@ -104,6 +108,7 @@ def cpu_baseline(args, pkg, cells):
             "host_cpu_count": os.cpu_count(),
             "host_cpus_usable": usable,
             "host_cpu_quota": quota,
+            "pinned_cpus": cpus,
             "sample": f"{reps} Chebyshev(k={args.degree})+FDM step() on {nc[0]}x{nc[1]}x{nc[2]} cells p=4 "
             f"({sm.n_dofs} DoFs, the bench mesh), C++ restatement oracle/asm_oracle_cpu.cc "
             f"({'-march=native' if native else '-march=x86-64-v3'}; blocks of 8x4x4 cells per thread and colour, SIMD batches of 8 cells), "

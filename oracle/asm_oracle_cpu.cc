@@ -28,6 +28,8 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -437,11 +439,34 @@ namespace
     explicit Pool(const int n)
       : n_(n)
     {
+      // ASM_ORACLE_CPUS = "c0,c1,...": thread t runs on CPU c[t mod size] (bench.py: one hardware thread per physical core,
+      // spread over the host's core complexes, when the process may use fewer CPUs than it sees); the caller's thread gets its
+      // own affinity back when the pool goes
+      if (const char *e = std::getenv("ASM_ORACLE_CPUS"))
+        for (const char *q = e; *q;)
+          {
+            char *     end = nullptr;
+            const long c   = std::strtol(q, &end, 10);
+            if (end == q)
+              break;
+            cpus_.push_back((int)c);
+            q = *end ? end + 1 : end;
+          }
+      if (!cpus_.empty())
+        {
+          have_old_ = pthread_getaffinity_np(pthread_self(), sizeof(old_), &old_) == 0;
+          pin(0);
+        }
       for (int t = 1; t < n_; ++t)
-        workers_.emplace_back([this, t]() { loop(t); });
+        workers_.emplace_back([this, t]() {
+          pin(t);
+          loop(t);
+        });
     }
     ~Pool()
     {
+      if (!cpus_.empty() && have_old_)
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(old_), &old_);
       {
         std::lock_guard<std::mutex> lk(m_);
         stop_ = true;
@@ -473,6 +498,16 @@ namespace
 
   private:
     void
+    pin(const int t) const
+    {
+      if (cpus_.empty())
+        return;
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      CPU_SET(cpus_[t % cpus_.size()], &set);
+      (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    void
     loop(const int t)
     {
       long seen = 0;
@@ -496,6 +531,9 @@ namespace
         }
     }
     int                             n_;
+    std::vector<int>                cpus_;
+    cpu_set_t                       old_;
+    bool                            have_old_ = false;
     std::vector<std::thread>        workers_;
     std::mutex                      m_;
     std::condition_variable         cv_, done_;
