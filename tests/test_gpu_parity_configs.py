@@ -91,6 +91,44 @@ def test_chebyshev_p4_m7(pkg, nc, bc, geometry, n_overlap, element_centric, weig
         assert rel(xv.get(), cheb.step(x0, b)) < TOL
 
 
+@pytest.mark.parametrize("lz", [None, "3"])
+@pytest.mark.parametrize(
+    "nc,bc,geometry,n_overlap,element_centric,weighting",
+    [
+        ((20, 9, 13), "dirichlet", "cartesian", 2, True, "post"),    # box 18 x 7 x 11: columns (9, 9) x (4, 3), z chunks (6, 5)
+        ((20, 10, 14), "periodic", "cartesian", 1, False, "symm"),   # vertex star, every cell in the box, wrap-around strips
+        ((19, 9, 13), ["periodic", "dirichlet", "neumann"], "cartesian", 2, True, "none"),
+        ((20, 6, 13), "dirichlet", "kershaw", 2, True, "post"),      # per-cell eigen-decompositions
+        ((11, 5, 8), "dirichlet", "cartesian", 2, True, "pre"),      # one column, a ragged second chunk
+    ],
+)
+def test_m7_accumulate_multi_column(pkg, monkeypatch, nc, bc, geometry, n_overlap, element_centric, weighting, lz):
+    """the accumulate form of the 7^3 sweep (fdm_slice7_acc_kernel) on meshes with several columns and z chunks, so that the
+    strips shared between workgroups (global atomics on values the init kernel wrote) and the DoFs a workgroup stores alone
+    both occur in every direction; plain product and the three fused Chebyshev updates (degree-3 step: first sweep,
+    x + f2 P^-1 r, three-term update onto x_old); ASM_S7_LZ=3 makes every chunk three layers"""
+    if lz:
+        monkeypatch.setenv("ASM_S7_LZ", lz)
+    mesh, ctx = make_pair(pkg, nc, 4, bc, geometry, eps=(0.3, 0.3), n_overlap=n_overlap, weighting=weighting,
+                          element_centric=element_centric, cheb_degree=3)
+    with ctx:
+        rng = np.random.default_rng(5)
+        src = rng.uniform(-1, 1, mesh.n_dofs)
+        prec = orc.ASPoissonPreconditioner(mesh, n_overlap, weighting, element_centric)
+        x, y = ctx.vector(src), ctx.vector(np.full(mesh.n_dofs, 123.0))
+        ctx.precond_vmult(y, x)
+        assert rel(y.get(), prec.vmult(src)) < TOL
+        cheb = orc.Chebyshev(orc.LaplaceOperator(mesh), prec, degree=3, lambda_max=1.7)
+        ctx.set_eigenvalue(1.7)
+        b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+        bv, xv = ctx.vector(b), ctx.vector()
+        ctx.cheb_vmult(xv, bv)
+        assert rel(xv.get(), cheb.vmult(b)) < TOL
+        xv.set(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), cheb.step(x0, b)) < TOL
+
+
 @pytest.mark.parametrize("nc,bc,geometry", [((3, 2, 2), "dirichlet", "kershaw"), ((2, 3, 2), ["dirichlet", "neumann", "dirichlet"], "kershaw"),
                                             ((4, 4, 4), "dirichlet", "kershaw")])
 def test_op_vmult_p7_deformed(pkg, nc, bc, geometry):
