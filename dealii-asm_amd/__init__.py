@@ -57,6 +57,7 @@ class AsmParams(C.Structure):
         ("world_size", C.c_int32),
         ("proc_grid", C.c_int32 * 3),
         ("polynomial_type", C.c_int32),
+        ("struct_size", C.c_uint32),
     ]
 
 
@@ -131,6 +132,7 @@ class AsmSolverParams(C.Structure):
         ("right_preconditioning", C.c_int32),
         ("max_n_tmp_vectors", C.c_int32),
         ("keep_preconditioned_basis", C.c_int32),
+        ("struct_size", C.c_uint32),
     ]
 
 

@@ -1098,6 +1098,7 @@ asm_params_default(asm_params *p)
   p->rank             = 0;
   p->world_size       = 1;
   p->polynomial_type  = ASM_POLY_FIRST_KIND;
+  p->struct_size = (uint32_t)sizeof(asm_params);
 }
 
 int

@@ -1207,6 +1207,7 @@ asm_solver_params_default(asm_solver_params *p)
   p->right_preconditioning = 1;
   p->max_n_tmp_vectors     = 30;
   p->keep_preconditioned_basis = 0;
+  p->struct_size = (uint32_t)sizeof(asm_solver_params);
 }
 
 const char *
@@ -1627,6 +1628,11 @@ asm_solve(asm_ctx *ctx, asm_mg *mg, int preconditioner, const asm_solver_params 
     asm_solver_params_default(&sp);
   std::string  local_error;
   std::string &error = mg ? mg->error : local_error;
+  if (sp_in && sp_in->struct_size != (uint32_t)sizeof(asm_solver_params))
+    {
+      error = "asm_solver_params of another ABI revision: fill it with asm_solver_params_default first";
+      return ASM_ERR_INVALID_VALUE;
+    }
   if (preconditioner == ASM_SP_MULTIGRID)
     {
       if (mg == nullptr)

@@ -144,6 +144,12 @@ namespace asmamd
   inline bool
   setup_layout(const asm_params &prm_in, HostSetup &s)
   {
+    if (prm_in.struct_size != (uint32_t)sizeof(asm_params))
+      {
+        s.error = "asm_params of another ABI revision (struct_size " + std::to_string(prm_in.struct_size) + ", expected " +
+                  std::to_string(sizeof(asm_params)) + "): fill it with asm_params_default first";
+        return false;
+      }
     s.prm            = prm_in;
     asm_params &prm  = s.prm;
     const int   p    = prm.degree;

@@ -152,6 +152,11 @@ typedef struct asm_params
 
   /* --- appended in ABI revision 2 --------------------------------------- */
   int32_t polynomial_type; /* asm_polynomial_type, "polynomial type", default "1st kind" */
+
+  /* --- appended in ABI revision 3 --------------------------------------- */
+  uint32_t struct_size; /* set by asm_params_default; every entry point that takes an asm_params refuses any other value (a
+                         * caller built against another revision of this header is told so instead of being read past its
+                         * end) */
 } asm_params;
 
 /* description of the device vector layout (replaces
@@ -476,6 +481,7 @@ typedef struct asm_solver_params
    * combination of the basis at the end of a cycle; 1 = keep the preconditioned basis vectors M^-1 v_i (as SolverFGMRES does):
    * one preconditioner application less per cycle for as many more work vectors; the same iterates for a linear preconditioner */
   int32_t keep_preconditioned_basis;
+  uint32_t struct_size; /* set by asm_solver_params_default; asm_solve refuses any other value */
 } asm_solver_params;
 typedef struct asm_solver_result
 {

@@ -146,3 +146,22 @@ def test_comm_init_error_path(pkg):
     lib = pkg.load_library()
     assert lib.asm_comm_init(None, b"\0" * 128) == 1
     assert "context and unique id" in lib.asm_last_error(None).decode()
+
+
+def test_params_of_another_abi_revision_are_refused(pkg):
+    """asm_params carries its size (set by asm_params_default): a structure that was not filled by it - a caller built
+    against another revision of the header - is refused by every entry point that takes one (no GPU needed for this one)"""
+    import ctypes as C
+
+    lib = pkg.load_library()
+    p = pkg.AsmParams()
+    lib.asm_params_default(C.byref(p))
+    assert p.struct_size == C.sizeof(pkg.AsmParams)
+    layout = pkg.AsmLayout()
+    assert lib.asm_describe_layout(C.byref(p), C.byref(layout)) == 0
+    p.struct_size = C.sizeof(pkg.AsmParams) - 4  # revision 2 ended before this field
+    assert lib.asm_describe_layout(C.byref(p), C.byref(layout)) == 1
+    assert "ABI revision" in lib.asm_last_error(None).decode()
+    sp = pkg.AsmSolverParams()
+    lib.asm_solver_params_default(C.byref(sp))
+    assert sp.struct_size == C.sizeof(pkg.AsmSolverParams)
