@@ -38,20 +38,27 @@ def _run_ranks(fn, n):
 
 
 CASES = [
-    # world, cells, degree, mg type, smoother weighting, n_overlap, intermediate smoother, expected distributed levels (coarse -> fine)
+    # world, cells, degree, mg type, smoother weighting, n_overlap, intermediate smoother, geometry (None = Cartesian)
     (2, (8, 4, 4), 4, "ph", "post", 1, ("Diagonal", 4), None),
     (4, (8, 8, 4), 4, "ph", "post", 1, None, None),
     (8, (8, 8, 8), 4, "ph", "symm", 1, ("Diagonal", 3), None),
     (2, (12, 4, 4), 3, "h", "post", 1, None, None),
     (4, (6, 6, 4), 4, "p", "post", 2, None, None),
     (2, (8, 4, 4), 2, "hp", "post", 1, None, None),
+    # BASELINE config 5's smoother on a partition: Kershaw mesh, p = 7, restricted additive Schwarz, n_overlap 2
+    (2, (4, 4, 4), 7, "ph", "ras", 2, None, "kershaw"),
+    (8, (4, 4, 4), 7, "p", "ras", 2, None, "kershaw"),
+    # ... and config 3's (Kershaw, p = 4, n_overlap 2, post)
+    (4, (8, 8, 4), 4, "ph", "post", 2, None, "kershaw"),
 ]
 
 
-@pytest.mark.parametrize("world,nc,p,mg_type,weighting,n_overlap,inter,_", CASES)
-def test_partitioned_hierarchy_reproduces_single_rank(world, nc, p, mg_type, weighting, n_overlap, inter, _):
+@pytest.mark.parametrize("world,nc,p,mg_type,weighting,n_overlap,inter,geometry", CASES)
+def test_partitioned_hierarchy_reproduces_single_rank(world, nc, p, mg_type, weighting, n_overlap, inter, geometry):
     pkg = load_package()
     kw = dict(degree=p, n_cells=nc, boundary="dirichlet", weighting=weighting, n_overlap=n_overlap, cheb_degree=2)
+    if geometry:
+        kw.update(geometry=geometry, kershaw_eps=(0.3, 0.3))
     mkw = dict(mg_type=mg_type, coarse="direct", intermediate_smoother=inter)
     single = pkg.Multigrid(pkg.make_params(**kw), **mkw)
     npd = [p * nc[d] + 1 for d in range(3)]
