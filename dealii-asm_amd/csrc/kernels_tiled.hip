@@ -152,6 +152,11 @@ namespace asmamd
     {
       int ntx, nty, nzc; // tiles in x, y; chunks in z
       int zlen;          // owned cell layers per chunk
+      // first cell of tile 0 in x / y: -1 where the block has a cell below its first one (periodic image, halo cell of
+      // the lower rank: tile 0 needs it as its halo column / row), 0 at a physical boundary - tile 0 then owns all its
+      // twelve columns / TY rows, which saves a whole column (row) of tiles when nc = 1 (mod owned cells per tile),
+      // e.g. 78 = 7 x 11 + 1 = 11 x 7 + 1: 7 x 11 instead of 8 x 12 tiles
+      int x_first, y_first;
       // Two-phase launches (TiledArgs::phase 1 / 2): the workgroups in "phase order": the boundary ones (up to six
       // slabs around the box of interior workgroups) first, then the interior box, each box in lexicographic order.
       // Phase 1 is the first n_first of them (all boundary workgroups, padded with interior ones to whole rounds of
@@ -391,7 +396,9 @@ namespace asmamd
         }
       // a cell is stored by the tile that holds it outside its halo row / column; the cell's
       // DoFs (0..3)^3 belong to it, the block's last plane to the last cell
-      const bool owned_cell = c.cell_xy && c.cl >= 1 && c.w >= 1;
+      // (the first column / row of a tile is its halo - unless nothing lies below it: Tiling::x_first, y_first)
+      const bool owned_cell = c.cell_xy && (c.cl >= 1 || (c.cx >= 0 && !cell_computable(g, 0, c.cx - 1))) &&
+                              (c.w >= 1 || (c.cy >= 0 && !cell_computable(g, 1, c.cy - 1)));
       const bool last_col   = !g.wrap[0] && g.own_hi[0] == g.nc[0] * P && c.cx == g.nc[0] - 1;
       const bool last_row   = !g.wrap[1] && g.own_hi[1] == g.nc[1] * P && c.cy == g.nc[1] - 1;
       c.own_row             = owned_cell && (c.sub < N1 - 1 || last_row);
@@ -1031,7 +1038,7 @@ namespace asmamd
 
       int tx, ty, zc;
       workgroup_of_block(a, tl, tx, ty, zc);
-      const int X0 = tx * OX - 1, Y0 = ty * OY - 1; // tile cell (0,0)
+      const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first; // tile cell (0,0)
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
@@ -1327,7 +1334,7 @@ namespace asmamd
 
       int tx, ty, zc;
       workgroup_of_block(a, tl, tx, ty, zc);
-      const int X0 = tx * OX - 1, Y0 = ty * OY - 1;
+      const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
@@ -1458,7 +1465,7 @@ namespace asmamd
 
       int tx, ty, zc;
       workgroup_of_block(a, tl, tx, ty, zc);
-      const int X0 = tx * OX - 1, Y0 = ty * T2::OYW - 1;
+      const int X0 = tx * OX + tl.x_first, Y0 = ty * T2::OYW + tl.y_first;
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
@@ -1547,8 +1554,11 @@ namespace asmamd
     {
       int    n_cu = a.n_cu;
       Tiling tl;
-      tl.ntx = (g.nc[0] + OX - 1) / OX;
-      tl.nty = (g.nc[1] + oy - 1) / oy;
+      tl.x_first = (g.wrap[0] || g.ext_lo[0] < 0) ? -1 : 0; // (cell_computable(g, d, -1))
+      tl.y_first = (g.wrap[1] || g.ext_lo[1] < 0) ? -1 : 0;
+      // tile t covers cells t OX + x_first ... + OX: the last one must hold cell nc - 1
+      tl.ntx = std::max(1, (g.nc[0] - 1 - tl.x_first + OX - 1) / OX);
+      tl.nty = std::max(1, (g.nc[1] - 1 - tl.y_first + oy - 1) / oy);
       tl.n_box = tl.n_first = 0;
       // the last owned plane nc*p of a non-wrapped direction is produced by the tile
       // that holds cell nc-1, no extra tile needed

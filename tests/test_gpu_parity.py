@@ -131,6 +131,13 @@ TILED_CASES = [
     ((4, 16, 5), ["periodic", "dirichlet", "dirichlet"], "cartesian"),
     ((6, 2, 2), "dirichlet", "kershaw"),
     ((18, 16, 2), "dirichlet", "kershaw"),
+    # cell counts of 1 modulo the owned cells of a tile (11 in x, 7 in y for 8-row tiles): at a physical boundary tile 0
+    # starts at cell 0 and owns its first column / row as well (Tiling::x_first, y_first) - one tile owning everything,
+    # two tiles per direction, a last tile with a single column
+    ((12, 8, 2), "dirichlet", "cartesian"),
+    ((23, 15, 2), "dirichlet", "cartesian"),
+    ((13, 9, 3), ["neumann", "dirichlet", "periodic"], "cartesian"),
+    ((12, 22, 2), "dirichlet", "kershaw"),
 ]
 
 
@@ -149,7 +156,7 @@ def test_precond_vmult_tiled(pkg, nc, bc, geometry, weighting):
 
 
 @pytest.mark.parametrize("degree", [1, 2, 3, 4])
-@pytest.mark.parametrize("nc,bc,geometry", TILED_CASES[:5])
+@pytest.mark.parametrize("nc,bc,geometry", TILED_CASES[:5] + TILED_CASES[6:])
 def test_chebyshev_tiled(pkg, nc, bc, geometry, degree):
     mesh, ctx = make_pair(pkg, nc, 4, bc, geometry, eps=(0.3, 0.3), kernel="tiled", weighting="post", cheb_degree=degree)
     with ctx:
@@ -164,5 +171,30 @@ def test_chebyshev_tiled(pkg, nc, bc, geometry, degree):
         ctx.cheb_vmult(xv, bv)
         assert rel(xv.get(), cheb.vmult(b)) < TOL
         xv.set(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), cheb.step(x0, b)) < TOL
+
+
+@pytest.mark.parametrize("rows", ["0", "9", "10", "11"])
+@pytest.mark.parametrize("nc,bc", [((13, 9, 3), ["neumann", "dirichlet", "periodic"]), ((12, 10, 2), "dirichlet"), ((23, 21, 2), "dirichlet"),
+                                   ((5, 19, 4), "periodic")])
+def test_laplace_row_variants(pkg, monkeypatch, nc, bc, rows):
+    """every variant of the tiled Laplace sweep (8 rows per workgroup = first generation, 9-11 = second generation;
+    ASM_TILED_ROWS fixes what the context otherwise measures), on meshes whose row counts are 1 modulo the owned rows of
+    the variants (8, 9, 10 owned rows: tile 0 at a physical boundary owns its first row too) and on a periodic one"""
+    monkeypatch.setenv("ASM_TILED_ROWS", rows)
+    mesh, ctx = make_pair(pkg, nc, 4, bc, kernel="tiled", weighting="post", cheb_degree=2)
+    with ctx:
+        assert ctx.tiled_laplace_rows() == (8 if rows == "0" else int(rows))
+        op = orc.LaplaceOperator(mesh)
+        rng = np.random.default_rng(3)
+        src = rng.uniform(-1, 1, mesh.n_dofs)
+        x, y = ctx.vector(src), ctx.vector(np.full(mesh.n_dofs, 5.0))
+        ctx.op_vmult(y, x)
+        assert rel(y.get(), op.vmult(src)) < TOL
+        cheb = orc.Chebyshev(op, orc.ASPoissonPreconditioner(mesh, 1, "post"), degree=2, lambda_max=1.9)
+        ctx.set_eigenvalue(1.9)
+        b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+        bv, xv = ctx.vector(b), ctx.vector(x0)
         ctx.cheb_step(xv, bv)
         assert rel(xv.get(), cheb.step(x0, b)) < TOL
