@@ -1039,6 +1039,16 @@ namespace asmamd
       int tx, ty, zc;
       workgroup_of_block(a, tl, tx, ty, zc);
       const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first; // tile cell (0,0)
+      // The waves above the block's last cell row (tiles of the last tile row: 80 rows = 8 + 10 x 7 + 2) have no cell: they
+      // end here.  s_barrier waits for the surviving waves of a workgroup only, so the others go on as a smaller workgroup
+      // (fewer waves at the LDS and in the vector-memory path per layer); the cooperative table loads below run over the
+      // surviving threads.
+#ifndef ASM_EARLY_EXIT
+#  define ASM_EARLY_EXIT 1
+#endif
+      const int nt_active = ASM_EARLY_EXIT ? min(TY, g.nc[1] - Y0) * 64 : NT;
+      if ((int)threadIdx.x >= nt_active)
+        return;
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
@@ -1050,7 +1060,7 @@ namespace asmamd
       double *S_inv = S_tab + LDS_TAB;
       // eigen tables of tensor-product meshes live in LDS (the launcher checks n_inst <= 16)
       if (TENSOR)
-        for (int e = threadIdx.x; e < f.n_inst * EIG; e += NT)
+        for (int e = threadIdx.x; e < f.n_inst * EIG; e += nt_active)
           S_tab[e] = f.eig[e];
       __syncthreads();
 
@@ -1122,7 +1132,7 @@ namespace asmamd
             {
               __syncthreads(); // the previous tables are no longer read
               const int nn = f.n_inst * f.n_inst * (N1 * NE);
-              for (int e = threadIdx.x; e < nn; e += NT)
+              for (int e = threadIdx.x; e < nn; e += nt_active)
                 S_inv[e] = f.inv_table[(long long)iz_u * nn + e];
               __syncthreads();
               iz_cached = iz_u;
@@ -1335,6 +1345,9 @@ namespace asmamd
       int tx, ty, zc;
       workgroup_of_block(a, tl, tx, ty, zc);
       const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
+      // (waves above the block's last cell row end here: see fdm_tiled_kernel)
+      if (ASM_EARLY_EXIT && (int)threadIdx.x >= min(TY, g.nc[1] - Y0) * 64)
+        return;
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
@@ -1466,6 +1479,9 @@ namespace asmamd
       int tx, ty, zc;
       workgroup_of_block(a, tl, tx, ty, zc);
       const int X0 = tx * OX + tl.x_first, Y0 = ty * T2::OYW + tl.y_first;
+      // (waves above the block's last cell row end here: see fdm_tiled_kernel)
+      if (ASM_EARLY_EXIT && (int)threadIdx.x >= min(TYW, g.nc[1] - Y0) * 64)
+        return;
 
       CellLane c;
       cell_lane_setup(g, X0, Y0, c);
