@@ -207,6 +207,7 @@ EXPORTED_SYMBOLS = [
     "asm_mg_prolongate_add",
     "asm_mg_restrict",
     "asm_mg_vmult",
+    "asm_tiled_plan",
     "asm_mg_coarse_failures",
     "asm_mg_graph_replays",
     "asm_mg_comm_init",
@@ -294,6 +295,8 @@ def load_library():
     lib.asm_mg_level_distributed.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.asm_mg_debug_after_loopback.argtypes = [C.c_void_p]
     lib.asm_mg_coarse_failures.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.asm_tiled_plan.argtypes = [C.POINTER(AsmParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+                                   C.POINTER(C.c_int32)]
     lib.asm_mg_graph_replays.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.asm_solver_params_default.argtypes = [C.POINTER(AsmSolverParams)]
     lib.asm_solver_params_default.restype = None
@@ -302,6 +305,19 @@ def load_library():
     lib.asm_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     _lib = lib
     return lib
+
+
+def tiled_plan(params, n_cu=256, rows=0):
+    """asm_tiled_plan: (plan dict, order list) of the degree-4 tiled sweeps for the block `params` describes (host only)"""
+    lib = load_library()
+    plan, n = (C.c_int32 * 8)(), C.c_int32()
+    cap = 1 << 16
+    order = (C.c_int32 * cap)()
+    err = lib.asm_tiled_plan(C.byref(params), n_cu, rows, plan, order, cap, C.byref(n))
+    if err:
+        raise ValueError(lib.asm_last_error(None).decode())
+    keys = ("ntx", "nty", "nzc", "zlen", "x_first", "y_first", "owned_x", "owned_y")
+    return dict(zip(keys, list(plan))), list(order[: n.value])
 
 
 def make_params(

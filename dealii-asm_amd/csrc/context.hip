@@ -1237,6 +1237,34 @@ asm_describe_layout(const asm_params *p, asm_layout *out)
 }
 
 int
+asm_tiled_plan(const asm_params *p, int32_t n_cu, int32_t rows, int32_t plan[8], int32_t *order, int32_t max_order, int32_t *n_order)
+{
+  if (p == nullptr || plan == nullptr || n_order == nullptr)
+    return ASM_ERR_INVALID_VALUE;
+  HostSetup s;
+  if (!setup_layout(*p, s))
+    {
+      g_create_error = s.error;
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (s.g.p != 4)
+    {
+      g_create_error = "asm_tiled_plan: the tiled sweeps exist for degree 4";
+      return ASM_ERR_NOT_SUPPORTED;
+    }
+  int out[8];
+  tiled_plan(s.g, n_cu, rows, out);
+  for (int i = 0; i < 8; ++i)
+    plan[i] = out[i];
+  std::vector<int> ord;
+  *n_order = tiled_order(s.g, n_cu, rows, ord);
+  if (order != nullptr)
+    for (int i = 0; i < std::min<int>(max_order, (int)ord.size()); ++i)
+      order[i] = ord[i];
+  return ASM_OK;
+}
+
+int
 asm_exchange_plan(const asm_params *p, int add, asm_exchange_step steps[3], int32_t *n_steps)
 {
   HostSetup s;

@@ -85,6 +85,9 @@ namespace asmamd
   // index (tile x fastest, then tile y, then z chunk) taken by launch position p, where every XCD keeps its contiguous range of
   // work indices (L2 locality) but takes the expensive ones first.  Returns the number of positions (0: nothing to reorder).
   int tiled_order(const DevGrid &g, int n_cu, int rows, std::vector<int> &order);
+  // the tiling itself (host side): out = {tiles x, tiles y, z chunks, layers per chunk, first cell of tile 0 in x, in y,
+  // owned cell columns per tile, owned cell rows per tile}
+  void tiled_plan(const DevGrid &g, int n_cu, int rows, int out[8]);
   bool laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st);
   bool fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st);
 

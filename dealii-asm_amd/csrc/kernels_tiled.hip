@@ -1711,6 +1711,23 @@ namespace asmamd
     }
   } // namespace
 
+  void
+  tiled_plan(const DevGrid &g, const int n_cu, const int rows, int out[8])
+  {
+    TiledArgs a{};
+    a.phase         = 0;
+    a.n_cu          = n_cu;
+    const Tiling tl = make_tiling(g, a, tile_rows_of(rows));
+    out[0] = tl.ntx;
+    out[1] = tl.nty;
+    out[2] = tl.nzc;
+    out[3] = tl.zlen;
+    out[4] = tl.x_first;
+    out[5] = tl.y_first;
+    out[6] = OX;
+    out[7] = tile_rows_of(rows);
+  }
+
   int
   tiled_order(const DevGrid &g, const int n_cu, const int rows, std::vector<int> &order)
   {

@@ -343,6 +343,13 @@ int asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_m
  * (allocated and freed by the call; read + written bytes per second, best of `reps` launches): what the device sustains
  * next to the 8 TB/s HBM peak the roofline fractions are quoted against */
 int asm_measure_copy_bandwidth(asm_ctx *ctx, int64_t bytes, int32_t reps, double *gb_per_s);
+/* Host-only (no GPU): the tiling of the degree-4 owner-computes sweeps for the block `p` describes, on a device of n_cu
+ * compute units, for the sweep variant of `rows` cell rows per workgroup (0 or 8: first generation = the FDM sweep; 9-11: the
+ * second-generation Laplace sweeps).  plan = {tiles x, tiles y, z chunks, layers per chunk, first cell of tile 0 in x, in y
+ * (-1: a cell lies below the block's first one, 0: physical boundary), owned cell columns, owned cell rows per tile};
+ * order[i] = work index taken by launch position i of a single-phase launch (*n_order entries, 0: launch order = work
+ * order).  Diagnostic: lets the tiling be checked without a device (tests/test_abi_cpu.py). */
+int asm_tiled_plan(const asm_params *p, int32_t n_cu, int32_t rows, int32_t plan[8], int32_t *order, int32_t max_order, int32_t *n_order);
 /* Cell rows (waves) per workgroup of the context's tiled Laplace sweep: 8 = first generation, 9 / 10 / 11 = second
  * (picked by a measurement at creation, or ASM_TILED_ROWS); 0 = no tiled Laplace sweep.  Reported by bench.py. */
 int asm_tiled_laplace_rows(const asm_ctx *ctx, int32_t *rows);

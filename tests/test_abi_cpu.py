@@ -165,3 +165,50 @@ def test_params_of_another_abi_revision_are_refused(pkg):
     sp = pkg.AsmSolverParams()
     lib.asm_solver_params_default(C.byref(sp))
     assert sp.struct_size == C.sizeof(pkg.AsmSolverParams)
+
+
+@pytest.mark.parametrize("rows", [0, 9, 10, 11])
+@pytest.mark.parametrize("nc,bc", [((80, 80, 80), "dirichlet"), ((78, 78, 78), "dirichlet"), ((128, 128, 96), "dirichlet"), ((128, 64, 64), "periodic"),
+                                   ((12, 8, 2), "dirichlet"), ((13, 9, 3), "dirichlet"), ((23, 15, 40), ["dirichlet", "periodic", "neumann"]),
+                                   ((1, 1, 1), "dirichlet"), ((100, 7, 33), ["periodic", "neumann", "dirichlet"])])
+def test_tiling_of_the_tiled_sweeps(pkg, nc, bc, rows):
+    """asm_tiled_plan (host only): the tiles of the degree-4 owner-computes sweeps own every cell column / row of the block
+    exactly once - tile t covers cells t * owned + first ... + owned and owns all but its first, which is its halo unless
+    nothing lies below it (tile 0 at a physical boundary: first = 0) -, the z chunks cover the layers once, and the work
+    order is a permutation that keeps every XCD's contiguous range of the work (kernels_tiled.hip: make_tiling, tiled_order)"""
+    prm = pkg.make_params(degree=4, n_cells=nc, boundary=bc)
+    plan, order = pkg.tiled_plan(prm, n_cu=256, rows=rows)
+    bcs = [bc] * 3 if isinstance(bc, str) else bc
+    assert plan["owned_y"] == (7 if rows == 0 else rows - 1) and plan["owned_x"] == 11
+    for d, (n_tiles, owned, first) in enumerate(((plan["ntx"], plan["owned_x"], plan["x_first"]), (plan["nty"], plan["owned_y"], plan["y_first"]))):
+        assert first == (-1 if bcs[d] == "periodic" else 0)
+        count = [0] * nc[d]
+        for t in range(n_tiles):
+            lo = t * owned + first
+            for c in range(lo, lo + owned + 1):
+                halo = c == lo and not (t == 0 and first == 0)
+                if 0 <= c < nc[d] and not halo:
+                    count[c] += 1
+            assert lo <= nc[d] - 1  # no tile beyond the block
+        assert count == [1] * nc[d], (d, count)
+    assert plan["nzc"] * plan["zlen"] >= nc[2] > (plan["nzc"] - 1) * plan["zlen"]
+    n = plan["ntx"] * plan["nty"] * plan["nzc"]
+    if order:
+        assert len(order) == n and sorted(order) == list(range(n))
+        for x in range(8):  # (xcd_remap: XCD x takes work indices [begin, begin + size))
+            begin, size = x * (n >> 3) + min(x, n & 7), (n >> 3) + (1 if x < (n & 7) else 0)
+            assert sorted(order[begin:begin + size]) == list(range(begin, begin + size))
+    else:
+        assert all(b != "dirichlet" for b in bcs) or n < 16
+
+
+def test_chunk_count_model_of_the_tiled_sweeps(pkg):
+    """the chunk count of a block with Dirichlet faces is never ONE chunk of the whole height when that leaves the launch
+    without a second workgroup per compute unit to balance with (round 2's model took 1 chunk of 96 layers for
+    128 x 128 x 96 cells); a periodic block keeps the rounds-only model (two chunks, 240 workgroups in one round)"""
+    plan, _ = pkg.tiled_plan(pkg.make_params(degree=4, n_cells=(128, 128, 96), boundary="dirichlet"))
+    assert 4 <= plan["nzc"] <= 16
+    plan, _ = pkg.tiled_plan(pkg.make_params(degree=4, n_cells=(80, 80, 80), boundary="dirichlet"))
+    assert plan["nzc"] == 8 and plan["zlen"] == 10
+    plan, _ = pkg.tiled_plan(pkg.make_params(degree=4, n_cells=(128, 64, 64), boundary="periodic"))
+    assert plan["nzc"] == 2
