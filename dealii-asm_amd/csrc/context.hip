@@ -7,6 +7,7 @@
 //   PreconditionChebyshev (deal.II)   configured at include/precondition.templates.h:89-158
 #include "../../include/dealii_asm_amd.h"
 #include "kernels.h"
+#include "kron.h"
 #include "setup.h"
 
 #include <hip/hip_runtime.h>
@@ -74,6 +75,9 @@ struct asm_ctx
   DevGrid                  g;
   DevFdm                   f;
   DevOp                    op;
+  // wave-pair sweeps (kernels_pair.hip) of a tiled context on a tensor-product mesh: tables of A and of P (valid = 0: the
+  // tiled kernels take the sweep); ASM_PAIR=0 switches them off
+  DevKron                  kron_a{}, kron_p{};
   std::vector<void *>      allocs;
   bool                     ras_direct = true; // ASM_RAS_ATOMICS: restricted additive Schwarz through the atomics path on one rank too
   std::vector<double *>    work_pool; // released solver work vectors (asm_work_vector_*), kept until asm_destroy
@@ -568,6 +572,31 @@ namespace
     return ASM_OK;
   }
 
+  // The wave-pair sweep where it applies (single-phase launches), with the constrained DoFs - which it neither reads nor
+  // writes - set from the untouched operands afterwards; false: not applicable, nothing launched
+  bool
+  pair_laplace(asm_ctx *ctx, const TiledArgs &t, hipStream_t st)
+  {
+    if (!pair_sweep(ctx->g, ctx->kron_a, t, st))
+      return false;
+    vec_constrained(ctx->g, t.mode == OP_PLAIN ? 0 : 2, t.dst, t.src, t.b, st); // 0, or r_c = b_c - x_c
+    return true;
+  }
+  bool
+  pair_fdm(asm_ctx *ctx, const TiledArgs &t, hipStream_t st)
+  {
+    if (!pair_sweep(ctx->g, ctx->kron_p, t, st))
+      return false;
+    FdmFused fu;
+    fu.mode  = t.mode;
+    fu.x     = t.x;
+    fu.x_old = t.x_old;
+    fu.f1    = t.f1;
+    fu.f2    = t.f2;
+    vec_constrained_fused(ctx->g, fu, t.dst, t.src, st); // unit rows of P^-1
+    return true;
+  }
+
   // launch a tiled sweep; inside cheb_run with several ranks: boundary workgroups, exchange of the
   // result beside the interior workgroups (unless nobody reads the result's ghosts afterwards)
   template <typename Launch>
@@ -643,7 +672,8 @@ namespace
         TiledArgs a{mode, src, dst, b, nullptr, nullptr, 0., 0.};
         prof_mark(ctx, 0, true);
         bool ok = false;
-        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t, hipStream_t st) { return laplace_tiled(ctx->g, ctx->op, t, st); }, &ok);
+        err     = launch_tiled_sweep(
+          ctx, a, [&](const TiledArgs &t, hipStream_t st) { return pair_laplace(ctx, t, st) || laplace_tiled(ctx->g, ctx->op, t, st); }, &ok);
         if (err)
           return err;
         if (ok)
@@ -723,7 +753,8 @@ namespace
         TiledArgs a{mode, src, dst, nullptr, x, x_old, f1, f2};
         prof_mark(ctx, 1, true);
         bool ok = false;
-        err     = launch_tiled_sweep(ctx, a, [&](const TiledArgs &t, hipStream_t st) { return fdm_tiled(ctx->g, ctx->f, t, st); }, &ok);
+        err     = launch_tiled_sweep(
+          ctx, a, [&](const TiledArgs &t, hipStream_t st) { return pair_fdm(ctx, t, st) || fdm_tiled(ctx->g, ctx->f, t, st); }, &ok);
         if (err)
           return err;
         prof_mark(ctx, 1, false);
@@ -1382,6 +1413,39 @@ asm_create(const asm_params *p, asm_ctx **out)
         op.M_small[q] = ctx->basis->M_ref[q];
         op.K_small[q] = ctx->basis->K_ref[q];
       }
+  // wave-pair sweeps: the tables of A (tiled Laplace contexts) and of P (tiled FDM contexts on tensor-product meshes)
+  {
+    const char *e        = std::getenv("ASM_PAIR");
+    const bool  use_pair = e == nullptr || std::atoi(e) != 0;
+    const auto  up_kron  = [&](const HostKron &hk, DevKron &dk) -> int {
+      dk.valid = 0;
+      if (!hk.valid)
+        return ASM_OK;
+      for (int d = 0; d < 3; ++d)
+        {
+          dk.n_cls[d] = hk.n_cls[d];
+          UP(hk.cls[d], &dk.cls[d]);
+        }
+      UP(hk.sym, &dk.sym);
+      UP(hk.mat, &dk.mat);
+      UP(hk.diag, &dk.diag);
+      dk.valid = 1;
+      return ASM_OK;
+    };
+    HostKron hk;
+    if (use_pair && s.laplace_tiled && build_kron_laplace(s, *ctx->basis, hk))
+      {
+        err = up_kron(hk, ctx->kron_a);
+        if (err)
+          return fail(err);
+      }
+    if (use_pair && s.fdm_tiled && build_kron_fdm(s, hk))
+      {
+        err = up_kron(hk, ctx->kron_p);
+        if (err)
+          return fail(err);
+      }
+  }
   // FDM data
   DevFdm &f = ctx->f;
   std::memset(&f, 0, sizeof(f));

@@ -122,6 +122,24 @@ namespace asmamd
     int           small;     // m <= 3: one thread per cell, the patch in registers (kernels_small.hip)
   };
 
+  // Tables of a "Kronecker-diagonal" cell operator  sum_cells R^T (Bz x By x Bx) diag(D) (Fz x Fy x Fx)^T R  on a
+  // tensor-product mesh, as the wave-pair sweep (kernels_pair.hip) applies it: the FDM preconditioner (F = diag(w_pre) Q,
+  // B = diag(w_post) Q, D = 1 / (lx + ly + lz)) and the Laplace operator on box cells (F = constrained rows of F_ref zeroed,
+  // B = F_ref, D = hy hz / hx la + hx hz / hy lb + hx hy / hz lc) differ in these tables only.  A cell's class per
+  // direction selects its matrices; the class triple selects the diagonal.  Device pointers.
+  constexpr int KRON_MAX_CLS    = 4;   // classes per direction
+  constexpr int KRON_MAT_STRIDE = 88;  // doubles per (direction, class): F[i][a] 25, B[i][a] 25, F even-odd 16, B even-odd 16
+  constexpr int KRON_DIAG_STRIDE = 128; // doubles per class triple: D[(b * 5 + a) * 5 + c]
+  struct DevKron
+  {
+    int           valid;
+    int           n_cls[3];
+    const int *   cls[3]; // [nc[d] + 2]: class of cell c at [c + 1]
+    const int *   sym;    // [3][KRON_MAX_CLS] 1: the columns 0..2 of F and B are even, 3..4 odd vectors
+    const double *mat;    // [3][KRON_MAX_CLS][KRON_MAT_STRIDE]
+    const double *diag;   // [clz][cly][clx][KRON_DIAG_STRIDE], KRON_MAX_CLS classes per direction
+  };
+
   // geometry + basis of the Laplace operator (device pointers)
   struct DevOp
   {

@@ -91,6 +91,14 @@ namespace asmamd
   bool laplace_tiled(const DevGrid &g, const DevOp &op, const TiledArgs &a, hipStream_t st);
   bool fdm_tiled(const DevGrid &g, const DevFdm &f, const TiledArgs &a, hipStream_t st);
 
+  // ---- wave-pair sweep (kernels_pair.hip), degree 4, cell patches / box cells on tensor-product meshes: two waves share a
+  //      tile of 8 x 8 cells (one lane per cell), march along z and apply the Kronecker-diagonal cell operator of the
+  //      tables k with the fused update of a.mode; single-phase launches only (false: not applicable, nothing launched).
+  //      Constrained DoFs are neither read nor written: the caller sets them (vec_constrained / vec_constrained_fused).
+  bool pair_sweep(const DevGrid &g, const DevKron &k, const TiledArgs &a, hipStream_t st);
+  // the tiling of the pair sweep (host side): out = {tiles x, tiles y, z chunks, layers per chunk, first cell x, first cell y}
+  void pair_plan(const DevGrid &g, int n_cu, int out[6]);
+
   // ---- vector kernels (kernels_vector.hip)
   // elementwise over the whole allocation
   void vec_residual(double *r, const double *b, long long n, hipStream_t st);                // r = b - r

@@ -1,0 +1,846 @@
+// Wave-pair sweep for degree 4 on tensor-product meshes (gfx950): the FDM additive-Schwarz preconditioner with cell
+// patches (n_overlap = 1) and the Laplace operator on box cells, both as the "Kronecker-diagonal" cell operator
+//   dst = update( sum_cells R^T (Bz x By x Bx) diag(D) (Fz x Fy x Fx)^T R src )
+// of the tables in DevKron (grid.h).  It replaces, like the tiled kernels (kernels_tiled.hip), the gather /
+// apply_inverse / scatter-add of ASPoissonPreconditioner::vmult_internal (include/matrix_free.h:1023-1062), the cell loop
+// of LaplaceOperatorMatrixFree::vmult (include/operator.h:1367-1430) and the pre/post lambdas of PreconditionChebyshev.
+//
+// Work decomposition (round 4; measurements behind it: profiles/r04_pair_design.txt)
+//   * ONE LANE PER CELL: a workgroup = two waves that share a tile of 8 x 8 cells (lane l of both waves = cell l) and
+//     march along z over a chunk of cell layers; the tile owns the DoFs of 7 x 7 cells (first column / row = halo,
+//     computed for their contributions only), every DoF is written exactly once by the lane that owns it: no atomics.
+//     With a whole cell per lane all three sweep directions are register FMA chains: no transposes.
+//   * A cell needs 125 values at once, more than a lane's arithmetic registers hold beside anything else.  So per cell
+//     layer wave r transforms two of the four NEW DoF planes in x-y (planes 1 + 2r, 2 + 2r; plane 0 is plane 4 of the
+//     layer below: its transform is kept), both write their planes to an LDS scratchpad (lane-strided addresses:
+//     conflict-free, no address arithmetic), each wave takes 13 / 12 of the 25 z columns through the z sweeps and the
+//     diagonal in place in the scratchpad, and transforms two of the four output planes back (planes 2r, 2r + 1; the
+//     contributions of two consecutive cells of a column to their common plane are added BEFORE the back transform:
+//     4 instead of 5 plane transforms each way).  Three barriers of two waves per layer, each wave alone on its SIMD.
+//   * Nothing is parked in registers, so the accumulation registers are free: they take the NEXT layer's source planes
+//     and update operands, requested a whole layer ahead by plain global loads into FIXED registers the compiler never
+//     sees (one wave per SIMD has no other wave to hide a miss behind).  Audit of every build: no v_accvgpr_* outside
+//     the asm statements above a27, no scratch (tools/audit_pair.sh).
+//   * Merges: x by a DPP row shift, y by ds_bpermute, z in the transformed space (carry of 13 values per lane).
+//   * The cells c = nc of a direction whose last DoF plane belongs to the block do not exist but OWN that plane (their
+//     column / row 0): they run along with a zero diagonal and store what they receive from their neighbours.
+//   * Constrained DoFs are neither read (the tables zero their rows) nor written; the caller sets them.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <utility>
+
+namespace asmamd
+{
+  namespace
+  {
+    constexpr int P = 4, N1 = 5, NE = 25;
+    constexpr int TX = 8, TY = 8, OX = TX - 1, OY = TY - 1;
+    constexpr int NZC = 13; // z columns of wave 0 (0..12); wave 1 takes 13..24
+
+    // LDS of a workgroup (doubles)
+    constexpr int L_X    = P * NE * 64;                                // scratchpad: slot (q, e) of lane l at (q * 25 + e) * 64 + l
+    constexpr int L_D    = KRON_MAX_CLS * KRON_MAX_CLS * KRON_DIAG_STRIDE; // diagonals of the current z class, [cly][clx]
+    constexpr int L_ZERO = 72;                                         // the diagonal of cells that are not computed: 13 columns of zeros
+    constexpr int L_M    = 3 * KRON_MAX_CLS * KRON_MAT_STRIDE;         // all matrices
+    constexpr int L_TOTAL = L_X + L_D + L_ZERO + L_M;
+    static_assert(2 * L_TOTAL * sizeof(double) <= 160 * 1024, "two workgroups per compute unit");
+
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    typedef dbl2   dbl2_u __attribute__((aligned(8)));
+    // LDS pointers carry their address space in the type: a generic pointer would compile to flat loads, which count in
+    // vmcnt as well and complete out of order - the kernel's wait counts assume that no flat instruction exists (audit)
+    typedef __attribute__((address_space(3))) double       *lds_ptr;
+    typedef const __attribute__((address_space(3))) double *lds_cptr;
+
+    struct PairTiling
+    {
+      int ntx, nty, nzc, zlen;
+      int x_first, y_first; // first cell of tile 0: -1 where the block has a cell below its first one, else 0
+    };
+
+    __device__ __forceinline__ bool
+    cell_computable(const DevGrid &g, const int d, const int c)
+    {
+      if (c < -1 || c >= g.nc[d])
+        return false;
+      if (c >= 0)
+        return true;
+      return g.wrap[d] || g.ext_lo[d] < 0; // periodic image or halo cell of the lower rank
+    }
+    // the cell behind the block's last one: it does not exist but owns the block's last DoF plane
+    __host__ __device__ __forceinline__ bool
+    has_phantom(const DevGrid &g, const int d)
+    {
+      return !g.wrap[d] && g.own_hi[d] == g.nc[d] * P;
+    }
+
+    template <typename T>
+    __device__ __forceinline__ T
+    uniform_load(const T *table, const int idx)
+    {
+      return ((const __attribute__((address_space(4))) T *)table)[__builtin_amdgcn_readfirstlane(idx)];
+    }
+
+    // ---- coefficient registers, read from the LDS copy of the tables (same address in all lanes of a class: broadcast)
+    // even-odd form: E[a][i] = q[i][a] (a, i < 3), O[a][i] = q[i][3 + a] (a, i < 2)
+    struct EoCoef
+    {
+      double e[9], o[4];
+      __device__ __forceinline__ explicit EoCoef(lds_cptr m)
+      {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          e[k] = m[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          o[k] = m[9 + k];
+      }
+      __device__ __forceinline__ double E(const int a, const int i) const { return e[a * 3 + i]; }
+      __device__ __forceinline__ double O(const int a, const int i) const { return o[a * 2 + i]; }
+    };
+    // full matrix [i][a] of ONE class (cells at a boundary have no even-odd form): wave-uniform, read from the table in
+    // global memory by scalar loads, so that its 25 numbers are scalar operands of the FMAs and cost no vector registers
+    // (the even-odd path leaves none to spare: the compiler must never spill into the accumulation registers, see below)
+    struct FullCoef
+    {
+      const __attribute__((address_space(4))) double *q;
+      __device__ __forceinline__ explicit FullCoef(const double *m)
+        : q((const __attribute__((address_space(4))) double *)m)
+      {}
+    };
+
+    // FWD: out[a] = sum_i q[i][a] in[i];  else out[i] = sum_a q[i][a] in[a]
+    template <bool FWD>
+    __device__ __forceinline__ void
+    line5(double &u0, double &u1, double &u2, double &u3, double &u4, const EoCoef &q)
+    {
+      if (FWD)
+        {
+          const double e0 = u0 + u4, e1 = u1 + u3, o0 = u0 - u4, o1 = u1 - u3, m = u2;
+          u0 = fma(q.E(0, 2), m, fma(q.E(0, 1), e1, q.E(0, 0) * e0));
+          u1 = fma(q.E(1, 2), m, fma(q.E(1, 1), e1, q.E(1, 0) * e0));
+          u2 = fma(q.E(2, 2), m, fma(q.E(2, 1), e1, q.E(2, 0) * e0));
+          u3 = fma(q.O(0, 1), o1, q.O(0, 0) * o0);
+          u4 = fma(q.O(1, 1), o1, q.O(1, 0) * o0);
+        }
+      else
+        {
+          const double E0 = fma(q.E(2, 0), u2, fma(q.E(1, 0), u1, q.E(0, 0) * u0));
+          const double E1 = fma(q.E(2, 1), u2, fma(q.E(1, 1), u1, q.E(0, 1) * u0));
+          const double E2 = fma(q.E(2, 2), u2, fma(q.E(1, 2), u1, q.E(0, 2) * u0));
+          const double O0 = fma(q.O(1, 0), u4, q.O(0, 0) * u3);
+          const double O1 = fma(q.O(1, 1), u4, q.O(0, 1) * u3);
+          u0              = E0 + O0;
+          u4              = E0 - O0;
+          u1              = E1 + O1;
+          u3              = E1 - O1;
+          u2              = E2;
+        }
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void
+    line5(double &u0, double &u1, double &u2, double &u3, double &u4, const FullCoef &c)
+    {
+      const __attribute__((address_space(4))) double *q = c.q;
+      double                                          o[N1];
+#pragma unroll
+      for (int a = 0; a < N1; ++a)
+        {
+          double s = (FWD ? q[0 * N1 + a] : q[a * N1 + 0]) * u0;
+          s        = fma(FWD ? q[1 * N1 + a] : q[a * N1 + 1], u1, s);
+          s        = fma(FWD ? q[2 * N1 + a] : q[a * N1 + 2], u2, s);
+          s        = fma(FWD ? q[3 * N1 + a] : q[a * N1 + 3], u3, s);
+          s        = fma(FWD ? q[4 * N1 + a] : q[a * N1 + 4], u4, s);
+          o[a]     = s;
+        }
+      u0 = o[0];
+      u1 = o[1];
+      u2 = o[2];
+      u3 = o[3];
+      u4 = o[4];
+    }
+    template <bool FWD, typename Q>
+    __device__ __forceinline__ void
+    sweep_x(double (&v)[NE], const Q &q)
+    {
+#pragma unroll
+      for (int j = 0; j < N1; ++j)
+        line5<FWD>(v[j * 5 + 0], v[j * 5 + 1], v[j * 5 + 2], v[j * 5 + 3], v[j * 5 + 4], q);
+    }
+    template <bool FWD, typename Q>
+    __device__ __forceinline__ void
+    sweep_y(double (&v)[NE], const Q &q)
+    {
+#pragma unroll
+      for (int i = 0; i < N1; ++i)
+        line5<FWD>(v[0 * 5 + i], v[1 * 5 + i], v[2 * 5 + i], v[3 * 5 + i], v[4 * 5 + i], q);
+    }
+
+    // The x and y matrices of a lane (its cell's classes): the even-odd forms in LDS [.. 50: F 16][66: B 16], per lane;
+    // lanes whose class has no even-odd form (nsx / nsy; any_*: some lane of the wave) are redone class by class with
+    // the full matrix of the class as scalar operands.
+    struct XYMatrices
+    {
+      lds_cptr      mx, my;
+      int           clx, cly;
+      bool          nsx, nsy, any_nsx, any_nsy;
+      const double *gx, *gy; // the tables of the x / y classes in global memory: [class][KRON_MAT_STRIDE]
+    };
+    // one sweep direction of a plane
+    template <bool FWD, bool XDIR>
+    __device__ __forceinline__ void
+    sweep_dir(double (&v)[NE], const XYMatrices &m)
+    {
+      const bool ns = XDIR ? m.nsx : m.nsy;
+      if (!ns)
+        {
+          const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 50 : 66));
+          if (XDIR)
+            sweep_x<FWD>(v, q);
+          else
+            sweep_y<FWD>(v, q);
+        }
+      if (XDIR ? m.any_nsx : m.any_nsy)
+        {
+          // (wave-uniform loop over the classes without an even-odd form that occur in the wave: none, or one)
+          const int          cls  = XDIR ? m.clx : m.cly;
+          unsigned long long todo = __ballot(ns);
+          while (todo != 0ull)
+            {
+              const int  c0   = __builtin_amdgcn_readlane(cls, __ffsll((long long)todo) - 1);
+              const bool mine = ns && cls == c0;
+              if (mine)
+                {
+                  const FullCoef q((XDIR ? m.gx : m.gy) + (long long)c0 * KRON_MAT_STRIDE + (FWD ? 0 : 25));
+                  if (XDIR)
+                    sweep_x<FWD>(v, q);
+                  else
+                    sweep_y<FWD>(v, q);
+                }
+              todo &= ~__ballot(mine);
+            }
+        }
+    }
+    // x-y transform of one plane v[j * 5 + i]: forward x then y with F, backward y then x with B
+    template <bool FWD>
+    __device__ __forceinline__ void
+    plane2d(double (&v)[NE], const XYMatrices &m)
+    {
+      if (FWD)
+        {
+          sweep_dir<true, true>(v, m);
+          sweep_dir<true, false>(v, m);
+        }
+      else
+        {
+          sweep_dir<false, false>(v, m);
+          sweep_dir<false, true>(v, m);
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // The next layer's source planes and update operands wait in FIXED accumulation registers which the compiler never
+    // sees; it takes a0.. upwards if it has to spill (audit: its v_accvgpr_* stay below a28, no scratch):
+    //   a[A_S0 .. +49], a[A_S1 .. +49]   the two source planes of this wave: row j at +10 j: x 0..1, x 2..3, x 4
+    //   a[A_XA0 .. +31], a[A_XA1 .. +31] first update operand of its two output planes: row j at +8 j
+    //   a[A_XB0 .. +31], a[A_XB1 .. +31] second update operand (three-term update); the prologue's plane 0 (50 registers)
+    // ---------------------------------------------------------------------------------------------------------------
+    constexpr int A_S0 = 28, A_S1 = 78, A_XA0 = 128, A_XA1 = 160, A_XB0 = 192, A_XB1 = 224, A_P0 = 192;
+    static_assert(A_XB1 + 32 == 256 && A_P0 + 50 <= 256, "accumulation register map");
+#define ASM_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+    __device__ __forceinline__ void
+    areg_reserve()
+    {
+      asm volatile("" ::: "a28", "a29", ASM_A10(3), ASM_A10(4), ASM_A10(5), ASM_A10(6), ASM_A10(7), ASM_A10(8), ASM_A10(9), ASM_A10(10), ASM_A10(11),
+                   ASM_A10(12), ASM_A10(13), ASM_A10(14), ASM_A10(15), ASM_A10(16), ASM_A10(17), ASM_A10(18), ASM_A10(19), ASM_A10(20), ASM_A10(21),
+                   ASM_A10(22), ASM_A10(23), ASM_A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
+    }
+#undef ASM_A10
+
+    // five values of DoF row J: x 0..3 from the row's offset, x 4 from its own (periodic seam)
+    template <int A0, int J>
+    __device__ __forceinline__ void
+    plane_request_row(const double *plane, const unsigned o, const unsigned o4)
+    {
+      asm volatile("global_load_dwordx4 a[%3:%4], %0, %2\n\t"
+                   "global_load_dwordx4 a[%5:%6], %0, %2 offset:16\n\t"
+                   "global_load_dwordx2 a[%7:%8], %1, %2" ::"v"(o),
+                   "v"(o4), "s"(plane), "n"(A0 + 10 * J), "n"(A0 + 10 * J + 3), "n"(A0 + 10 * J + 4), "n"(A0 + 10 * J + 7), "n"(A0 + 10 * J + 8),
+                   "n"(A0 + 10 * J + 9)
+                   : "memory");
+    }
+    template <int A0, int J>
+    __device__ __forceinline__ void
+    operand_request_row(const double *plane, const unsigned o)
+    {
+      asm volatile("global_load_dwordx4 a[%2:%3], %0, %1\n\t"
+                   "global_load_dwordx4 a[%4:%5], %0, %1 offset:16" ::"v"(o),
+                   "s"(plane), "n"(A0 + 8 * J), "n"(A0 + 8 * J + 3), "n"(A0 + 8 * J + 4), "n"(A0 + 8 * J + 7)
+                   : "memory");
+    }
+    // everything but the N youngest vector memory operations of the wave has completed
+    template <int N>
+    __device__ __forceinline__ void
+    vm_wait()
+    {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    }
+    template <int A>
+    __device__ __forceinline__ double
+    areg_double()
+    {
+      int lo, hi;
+      asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(lo), "=v"(hi) : "n"(A), "n"(A + 1));
+      return __hiloint2double(hi, lo);
+    }
+    template <int A0, int... E>
+    __device__ __forceinline__ void
+    aregs_to(double *v, std::integer_sequence<int, E...>)
+    {
+      ((v[E] = areg_double<A0 + 2 * E>()), ...); // element E of a block of doubles at a[A0 + 2 E]
+    }
+    template <int A0>
+    __device__ __forceinline__ void
+    plane_unpack(double (&v)[NE])
+    {
+      aregs_to<A0 + 0>(&v[0], std::make_integer_sequence<int, 5>());
+      aregs_to<A0 + 10>(&v[5], std::make_integer_sequence<int, 5>());
+      aregs_to<A0 + 20>(&v[10], std::make_integer_sequence<int, 5>());
+      aregs_to<A0 + 30>(&v[15], std::make_integer_sequence<int, 5>());
+      aregs_to<A0 + 40>(&v[20], std::make_integer_sequence<int, 5>());
+    }
+    // ---------------------------------------------------------------------------------------------------------------
+    struct Lane
+    {
+      bool cell_xy;           // the cell is computed
+      bool owner;             // the lane stores DoFs (its cell, or the cell that does not exist but owns the last plane)
+      bool ph_x, ph_y;        // ... of which only column 0 / row 0 exist
+      bool xd0, yd0;          // column 0 / row 0 is a Dirichlet plane: not stored
+      bool left_ok, below_ok; // the lane to the left / below belongs to the tile
+      unsigned srow8[N1];     // source: byte offset of DoF row j of the cell inside a plane (cells not computed: cell 0)
+      unsigned sd4;           // ... and the step from column 0 to column 4 (periodic seam), bytes
+      unsigned orow8[P];      // operands / dst: byte offset of DoF row j of the DoFs the lane owns
+    };
+
+    template <int A0>
+    __device__ __forceinline__ void
+    plane_request(const double *plane, const Lane &c)
+    {
+      plane_request_row<A0, 0>(plane, c.srow8[0], c.srow8[0] + c.sd4);
+      plane_request_row<A0, 1>(plane, c.srow8[1], c.srow8[1] + c.sd4);
+      plane_request_row<A0, 2>(plane, c.srow8[2], c.srow8[2] + c.sd4);
+      plane_request_row<A0, 3>(plane, c.srow8[3], c.srow8[3] + c.sd4);
+      plane_request_row<A0, 4>(plane, c.srow8[4], c.srow8[4] + c.sd4);
+    }
+    template <int A0>
+    __device__ __forceinline__ void
+    operand_request(const double *plane, const Lane &c)
+    {
+      operand_request_row<A0, 0>(plane, c.orow8[0]);
+      operand_request_row<A0, 1>(plane, c.orow8[1]);
+      operand_request_row<A0, 2>(plane, c.orow8[2]);
+      operand_request_row<A0, 3>(plane, c.orow8[3]);
+    }
+
+    template <int MODE>
+    struct ModeTraits
+    {
+      static constexpr bool need_a = (MODE == OP_RESIDUAL || MODE == PC_STEP1 || MODE == PC_UPDATE);
+      static constexpr bool need_b = (MODE == PC_UPDATE);
+      static constexpr int  n_operand_requests = (need_a ? 16 : 0) + (need_b ? 16 : 0); // per wave and layer
+    };
+    template <int MODE>
+    __device__ __forceinline__ double
+    fused_update(const TiledArgs &a, const double t, const double oa, const double ob)
+    {
+      if (MODE == OP_PLAIN || MODE == PC_PLAIN)
+        return t;
+      if (MODE == OP_RESIDUAL)
+        return oa - t;
+      if (MODE == PC_FIRST)
+        return a.f2 * t;
+      if (MODE == PC_STEP1)
+        return a.f1 * oa + a.f2 * t;
+      return oa + a.f1 * (oa - ob) + a.f2 * t;
+    }
+
+    // value of lane - 1 inside a row of 16 lanes (DPP row_shr:1; the first lane of a row reads 0)
+    __device__ __forceinline__ double
+    lane_left(const double x)
+    {
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x111, 0xf, 0xf, true);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x111, 0xf, 0xf, true);
+      return __hiloint2double(hi, lo);
+    }
+
+    // fused update and store of DoF row J of a plane: the operands come out of the accumulation registers row by row
+    template <int MODE, int J, int AXA, int AXB>
+    __device__ __forceinline__ void
+    emit_row(const TiledArgs &a, const Lane &c, double *__restrict__ dplane, const double (&o)[NE])
+    {
+      using MT = ModeTraits<MODE>;
+      if (J == 0 ? !c.yd0 : !c.ph_y)
+        {
+          double xa[P] = {0., 0., 0., 0.}, xb[P] = {0., 0., 0., 0.};
+          if (MT::need_a)
+            aregs_to<AXA + 8 * J>(xa, std::make_integer_sequence<int, P>());
+          if (MT::need_b)
+            aregs_to<AXB + 8 * J>(xb, std::make_integer_sequence<int, P>());
+          double *const d = (double *)((char *)dplane + c.orow8[J]);
+          dbl2          lo, hi;
+          lo.x = fused_update<MODE>(a, o[J * 5 + 0], xa[0], xb[0]);
+          lo.y = fused_update<MODE>(a, o[J * 5 + 1], xa[1], xb[1]);
+          hi.x = fused_update<MODE>(a, o[J * 5 + 2], xa[2], xb[2]);
+          hi.y = fused_update<MODE>(a, o[J * 5 + 3], xa[3], xb[3]);
+          if (c.ph_x)
+            {
+              if (!c.xd0)
+                __builtin_nontemporal_store(lo.x, d);
+            }
+          else if (c.xd0)
+            {
+              __builtin_nontemporal_store(lo.y, d + 1);
+              __builtin_nontemporal_store(hi, (dbl2_u *)(d + 2));
+            }
+          else
+            {
+              __builtin_nontemporal_store(lo, (dbl2_u *)d);
+              __builtin_nontemporal_store(hi, (dbl2_u *)(d + 2));
+            }
+        }
+    }
+
+    // merges in x and y, fused update and store of the DoFs of one plane (at dst + plane offset) the lane owns;
+    // o[j * 5 + i] is consumed.  Cells that are not computed hold exact zeros (zero diagonal).
+    template <int MODE, int AXA, int AXB>
+    __device__ __forceinline__ void
+    emit_plane(const TiledArgs &a, const Lane &c, double *__restrict__ dplane, double (&o)[NE], const bool plane_constrained)
+    {
+      // x: column 4 of the left cell -> column 0
+#pragma unroll
+      for (int j = 0; j < N1; ++j)
+        {
+          const double r = lane_left(o[j * 5 + 4]);
+          if (c.left_ok)
+            o[j * 5 + 0] += r;
+        }
+      // y: row 4 of the cell below -> row 0
+      double rb[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        rb[i] = __shfl_up(o[4 * 5 + i], TX, 64);
+      if (c.below_ok)
+        {
+#pragma unroll
+          for (int i = 0; i < P; ++i)
+            o[0 * 5 + i] += rb[i];
+        }
+      if (c.owner && !plane_constrained)
+        {
+          emit_row<MODE, 0, AXA, AXB>(a, c, dplane, o);
+          emit_row<MODE, 1, AXA, AXB>(a, c, dplane, o);
+          emit_row<MODE, 2, AXA, AXB>(a, c, dplane, o);
+          emit_row<MODE, 3, AXA, AXB>(a, c, dplane, o);
+        }
+    }
+
+    // storage offset (doubles) of DoF plane K
+    __device__ __forceinline__ long long
+    plane_offset(const DevGrid &g, const int K)
+    {
+      return g.store_index_near(2, K) * g.stride[2];
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    template <int MODE>
+    __global__ void __launch_bounds__(128) pair_sweep_kernel(const DevGrid g, const DevKron kr, const TiledArgs a, const PairTiling tl)
+    {
+      extern __shared__ __attribute__((aligned(16))) double lds[];
+      using MT = ModeTraits<MODE>;
+      // workgroups b and b + 8 land on the same XCD: contiguous ranges of the work per XCD (L2 locality of neighbouring tiles)
+      const int wi = (int)xcd_block(blockIdx.x, gridDim.x);
+      const int tx = wi % tl.ntx, ty = (wi / tl.ntx) % tl.nty, zc = wi / (tl.ntx * tl.nty);
+      const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
+
+      const int lane = threadIdx.x & 63, cl = lane % TX, rw = lane / TX;
+      const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 / 1, wave-uniform
+      const int cx = X0 + cl, cy = Y0 + rw;
+      Lane      c;
+      int       clx = 0, cly = 0;
+      {
+        const bool comp_x = cell_computable(g, 0, cx), comp_y = cell_computable(g, 1, cy);
+        c.ph_x            = cx == g.nc[0] && has_phantom(g, 0);
+        c.ph_y            = cy == g.nc[1] && has_phantom(g, 1);
+        c.cell_xy         = comp_x && comp_y;
+        // a cell's DoFs (0..3)^2 belong to the tile that holds it outside its halo column / row; cells -1 are never owned
+        const bool own_x = cx >= 0 && (comp_x || c.ph_x) && (cl >= 1 || (tx == 0 && tl.x_first == 0));
+        const bool own_y = cy >= 0 && (comp_y || c.ph_y) && (rw >= 1 || (ty == 0 && tl.y_first == 0));
+        c.owner          = own_x && own_y;
+        c.left_ok        = cl >= 1;
+        c.below_ok       = rw >= 1;
+        c.xd0            = c.owner && g.dirichlet(0, P * cx);
+        c.yd0            = c.owner && g.dirichlet(1, P * cy);
+        // source rows: the cell itself, or cell (0, 0) for lanes without a computed cell (any finite data: zero diagonal)
+        const int sx = c.cell_xy ? cx : 0, sy = c.cell_xy ? cy : 0;
+        const int x0 = g.store_index_near(0, P * sx);
+        c.sd4        = (unsigned)(g.store_index_near(0, P * sx + P) - x0) * 8u;
+#pragma unroll
+        for (int j = 0; j < N1; ++j)
+          c.srow8[j] = (unsigned)(g.store_index_near(1, P * sy + j) * (int)g.stride[1] + x0) * 8u;
+        // owned rows: rows 1..3 of a cell that only owns row 0 do not exist
+        const int ox = c.owner ? cx : 0, oy = c.owner ? cy : 0;
+        const int xo = g.store_index_near(0, P * ox);
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+          c.orow8[j] = (unsigned)(g.store_index_near(1, P * oy + ((c.owner && c.ph_y) ? 0 : j)) * (int)g.stride[1] + xo) * 8u;
+        if (c.cell_xy)
+          {
+            clx = kr.cls[0][cx + 1];
+            cly = kr.cls[1][cy + 1];
+          }
+      }
+
+      const lds_ptr Xl = (lds_ptr)lds + lane;
+      const lds_ptr Dl = (lds_ptr)lds + L_X;
+      const lds_ptr Zl = Dl + L_D;
+      const lds_ptr Ml = Zl + L_ZERO;
+      for (int e = threadIdx.x; e < L_M; e += 128)
+        Ml[e] = kr.mat[e];
+      for (int e = threadIdx.x; e < L_ZERO; e += 128)
+        Zl[e] = 0.;
+      XYMatrices mxy;
+      mxy.mx      = Ml + (0 * KRON_MAX_CLS + clx) * KRON_MAT_STRIDE;
+      mxy.my      = Ml + (1 * KRON_MAX_CLS + cly) * KRON_MAT_STRIDE;
+      mxy.clx     = clx;
+      mxy.cly     = cly;
+      mxy.nsx     = c.cell_xy && kr.sym[0 * KRON_MAX_CLS + clx] == 0;
+      mxy.nsy     = c.cell_xy && kr.sym[1 * KRON_MAX_CLS + cly] == 0;
+      mxy.any_nsx = __any(mxy.nsx);
+      mxy.any_nsy = __any(mxy.nsy);
+      mxy.gx      = kr.mat + 0 * KRON_MAX_CLS * KRON_MAT_STRIDE;
+      mxy.gy      = kr.mat + 1 * KRON_MAX_CLS * KRON_MAT_STRIDE;
+      // this lane's diagonal: column e of this wave at Dz + 5 e (cells that are not computed: zeros)
+      const int      col0 = NZC * role;
+      const lds_cptr Dz   = c.cell_xy ? Dl + (cly * KRON_MAX_CLS + clx) * KRON_DIAG_STRIDE + col0 * N1 : Zl;
+
+      // scratchpad addresses of this lane: forward planes of this wave, its z columns, its backward planes
+      const lds_ptr X_fwd = Xl + (2 * role) * NE * 64;
+      const lds_ptr X_z   = Xl + col0 * 64;
+      const lds_ptr X_bwd = Xl + (2 * role) * NE * 64;
+      const int     kf = 1 + 2 * role, kb = 2 * role; // first forward / backward plane of this wave
+
+      const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
+      const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
+
+      const double *const opA = (MODE == OP_RESIDUAL) ? a.b : a.x;
+
+      double t0[NZC], carry[NZC];
+#pragma unroll
+      for (int e = 0; e < NZC; ++e)
+        carry[e] = 0.;
+
+      areg_reserve();
+      __syncthreads(); // tables in LDS
+      int clz_cached = -1;
+      // ---- prologue: plane 0 of the first layer (wave 0 transforms it, both pick their columns), first requests
+      {
+        const long long z0 = plane_offset(g, P * z_first);
+        plane_request<A_P0>(a.src + z0, c);
+        plane_request<A_S0>(a.src + plane_offset(g, P * z_first + kf), c);
+        plane_request<A_S1>(a.src + plane_offset(g, P * z_first + kf + 1), c);
+        if (MT::need_a && z_first >= Zb)
+          {
+            operand_request<A_XA0>(opA + plane_offset(g, P * z_first + kb), c);
+            operand_request<A_XA1>(opA + plane_offset(g, P * z_first + kb + 1), c);
+          }
+        vm_wait<0>();
+        double v[NE];
+        plane_unpack<A_P0>(v);
+        if (MT::need_b && z_first >= Zb)
+          {
+            operand_request<A_XB0>(a.x_old + plane_offset(g, P * z_first + kb), c);
+            operand_request<A_XB1>(a.x_old + plane_offset(g, P * z_first + kb + 1), c);
+          }
+        plane2d<true>(v, mxy);
+        if (role == 0)
+          {
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+              Xl[e * 64] = v[e];
+          }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NZC; ++e)
+          t0[e] = (e < NZC - 1 || role == 0) ? X_z[e * 64] : 0.;
+        __syncthreads();
+      }
+
+      for (int cz = z_first; cz < Ze; ++cz)
+        {
+          const bool emit = cz >= Zb, more = cz + 1 < Ze;
+          // the diagonals of this layer's z class
+          const int clz = uniform_load(kr.cls[2], cz + 1);
+          if (clz != clz_cached)
+            {
+              // (the scratchpad barriers below order these writes against the reads of the layer before)
+              const double *src = kr.diag + (long long)clz * L_D;
+              for (int e = threadIdx.x; e < L_D; e += 128)
+                Dl[e] = src[e];
+              clz_cached = clz;
+            }
+          // ---- forward x-y transforms of this wave's two planes -> scratchpad
+          {
+            if (cz == z_first || cz == Zb || MT::n_operand_requests == 0)
+              vm_wait<0>(); // first layers of a chunk, or nothing but the stores of the layer below is younger
+            else
+              vm_wait<MT::n_operand_requests>(); // younger than the plane requests: the operand requests of this layer
+            {
+              double v[NE];
+              plane_unpack<A_S0>(v);
+              plane2d<true>(v, mxy);
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                X_fwd[(0 * NE + e) * 64] = v[e];
+            }
+            {
+              double v[NE];
+              plane_unpack<A_S1>(v);
+              plane2d<true>(v, mxy);
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                X_fwd[(1 * NE + e) * 64] = v[e];
+            }
+            // the next layer's planes: a whole layer ahead
+            if (more)
+              {
+                plane_request<A_S0>(a.src + plane_offset(g, P * (cz + 1) + kf), c);
+                plane_request<A_S1>(a.src + plane_offset(g, P * (cz + 1) + kf + 1), c);
+              }
+          }
+          const lds_cptr      mz    = Ml + (2 * KRON_MAX_CLS + clz) * KRON_MAT_STRIDE;
+          const bool          eo_z  = uniform_load(kr.sym, 2 * KRON_MAX_CLS + clz) != 0;
+          __syncthreads();
+          // ---- z sweeps of this wave's columns and the diagonal, in place in the scratchpad; reads run one column ahead
+          {
+            double n1 = X_z[(0 * NE) * 64], n2 = X_z[(1 * NE) * 64], n3 = X_z[(2 * NE) * 64], n4 = X_z[(3 * NE) * 64];
+            double nd[N1];
+#pragma unroll
+            for (int cc = 0; cc < N1; ++cc)
+              nd[cc] = Dz[cc];
+            const auto columns = [&](const auto &qf, const auto &qb) {
+#pragma unroll
+              for (int e = 0; e < NZC; ++e)
+                if (e < NZC - 1 || role == 0)
+                  {
+                    double       u0 = t0[e], u1 = n1, u2 = n2, u3 = n3, u4 = n4;
+                    const double d0 = nd[0], d1 = nd[1], d2 = nd[2], d3 = nd[3], d4 = nd[4];
+                    if (e + 1 < NZC && (e + 1 < NZC - 1 || role == 0))
+                      {
+                        n1 = X_z[(0 * NE + e + 1) * 64];
+                        n2 = X_z[(1 * NE + e + 1) * 64];
+                        n3 = X_z[(2 * NE + e + 1) * 64];
+                        n4 = X_z[(3 * NE + e + 1) * 64];
+#pragma unroll
+                        for (int cc = 0; cc < N1; ++cc)
+                          nd[cc] = Dz[(e + 1) * N1 + cc];
+                      }
+                    t0[e] = u4;
+                    line5<true>(u0, u1, u2, u3, u4, qf);
+                    u0 *= d0;
+                    u1 *= d1;
+                    u2 *= d2;
+                    u3 *= d3;
+                    u4 *= d4;
+                    line5<false>(u0, u1, u2, u3, u4, qb);
+                    if (emit)
+                      {
+                        X_z[(0 * NE + e) * 64] = u0 + carry[e];
+                        X_z[(1 * NE + e) * 64] = u1;
+                        X_z[(2 * NE + e) * 64] = u2;
+                        X_z[(3 * NE + e) * 64] = u3;
+                      }
+                    carry[e] = u4;
+                  }
+            };
+            if (eo_z)
+              columns(EoCoef(mz + 50), EoCoef(mz + 66));
+            else
+              {
+                // first / last layer of a block with Dirichlet or Neumann faces: full matrices, scalar operands
+                const double *gz = kr.mat + (long long)(2 * KRON_MAX_CLS + clz) * KRON_MAT_STRIDE;
+                columns(FullCoef(gz), FullCoef(gz + 25));
+              }
+          }
+          __syncthreads();
+          if (emit)
+            {
+              // ---- backward x-y transforms of this wave's two output planes, merge, update, store
+              const long long zo0 = plane_offset(g, P * cz + kb), zo1 = zo0 + g.stride[2]; // (planes 0..3 of a layer are consecutive)
+              const bool      con0 = g.dirichlet(2, P * cz + kb);                           // (only plane 0 of a layer can be one)
+              double          w[NE];
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                w[e] = X_bwd[(0 * NE + e) * 64];
+              if (cz == Zb || !more)
+                vm_wait<0>();
+              else
+                vm_wait<30>(); // younger than the operand requests: the 30 plane requests of this layer
+              plane2d<false>(w, mxy);
+              emit_plane<MODE, A_XA0, A_XB0>(a, c, a.dst + zo0, w, con0);
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                w[e] = X_bwd[(1 * NE + e) * 64];
+              __syncthreads(); // the scratchpad may take the next layer's planes
+              plane2d<false>(w, mxy);
+              emit_plane<MODE, A_XA1, A_XB1>(a, c, a.dst + zo1, w, false);
+            }
+          else
+            __syncthreads();
+          if (more)
+            {
+              // the next layer's update operands
+              if (MT::need_a)
+                {
+                  operand_request<A_XA0>(opA + plane_offset(g, P * (cz + 1) + kb), c);
+                  operand_request<A_XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                }
+              if (MT::need_b)
+                {
+                  operand_request<A_XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
+                  operand_request<A_XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                }
+            }
+        }
+      if (Ze == g.nc[2] && has_phantom(g, 2))
+        {
+          // top plane of the block: what the last layer left in the carries of both waves, transformed back by wave 0
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < NZC; ++e)
+            if (e < NZC - 1 || role == 0)
+              X_z[e * 64] = carry[e];
+          __syncthreads();
+          if (role == 0 && !g.dirichlet(2, P * g.nc[2]))
+            {
+              double v[NE];
+#pragma unroll
+              for (int e = 0; e < NE; ++e)
+                v[e] = Xl[e * 64];
+              const long long zo = plane_offset(g, P * g.nc[2]);
+              if (MT::need_a)
+                operand_request<A_XA0>(opA + zo, c);
+              if (MT::need_b)
+                operand_request<A_XB0>(a.x_old + zo, c);
+              vm_wait<0>();
+              plane2d<false>(v, mxy);
+              emit_plane<MODE, A_XA0, A_XB0>(a, c, a.dst + zo, v, false);
+            }
+        }
+    }
+
+    // ---- host side ------------------------------------------------------------------------------------------------
+    PairTiling
+    make_pair_tiling(const DevGrid &g, const int n_cu_in)
+    {
+      PairTiling tl;
+      const int  n_cu  = n_cu_in > 0 ? n_cu_in : 256;
+      const auto first = [&](const int d) { return (g.wrap[d] || g.ext_lo[d] < 0) ? -1 : 0; };
+      const auto tiles = [&](const int d, const int first_cell, const int owned) {
+        const int last = g.nc[d] - 1 + (has_phantom(g, d) ? 1 : 0); // last cell that owns DoFs
+        // tile t owns the cells first + t owned + 1 .. first + (t + 1) owned, tile 0 also its first column if that is cell 0
+        int n = 1;
+        while (first_cell + n * owned < last)
+          ++n;
+        return n;
+      };
+      tl.x_first = first(0);
+      tl.y_first = first(1);
+      tl.ntx     = tiles(0, tl.x_first, OX);
+      tl.nty     = tiles(1, tl.y_first, OY);
+      // z chunks: two workgroups per compute unit run at a time; a chunk costs its layers plus the halo layer below it.
+      // Fewest rounds x layers; ties: fewer chunks (fewer halo layers)
+      const long long slots  = 2ll * n_cu, tiles_xy = (long long)tl.ntx * tl.nty;
+      const bool      halo_z = g.wrap[2] || g.ext_lo[2] < 0;
+      int             best = 1;
+      double          best_cost = 1e300;
+      if (const char *e = std::getenv("ASM_PAIR_ZCHUNKS"))
+        best = std::max(1, std::min(std::atoi(e), g.nc[2]));
+      else
+        for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
+          {
+            const int       zlen   = (g.nc[2] + nzc - 1) / nzc;
+            const int       chunks = (g.nc[2] + zlen - 1) / zlen;
+            const long long wgs    = tiles_xy * chunks;
+            const double    rounds = (double)((wgs + slots - 1) / slots);
+            // (average of whole and fractional rounds: compute units take new workgroups as they fall free)
+            const double cost = 0.5 * (rounds + (double)wgs / slots) * (zlen + ((chunks > 1 || halo_z) ? 1.0 : 0.0) + 0.5);
+            if (cost < best_cost - 1e-9)
+              {
+                best_cost = cost;
+                best      = chunks;
+              }
+          }
+      tl.zlen = (g.nc[2] + best - 1) / best;
+      tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
+      return tl;
+    }
+
+    template <int MODE>
+    bool
+    launch_pair(const DevGrid &g, const DevKron &k, const TiledArgs &a, const PairTiling &tl, hipStream_t st)
+    {
+      static std::atomic<unsigned long long> done{0};
+      const unsigned long long               bit = 1ull << (a.device & 63);
+      if (!(done.load(std::memory_order_acquire) & bit))
+        {
+          if (hipFuncSetAttribute((const void *)pair_sweep_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(L_TOTAL * sizeof(double))) != hipSuccess)
+            {
+              (void)hipGetLastError();
+              return false;
+            }
+          done.fetch_or(bit, std::memory_order_release);
+        }
+      hipLaunchKernelGGL((pair_sweep_kernel<MODE>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(128), L_TOTAL * sizeof(double), st, g, k, a, tl);
+      return true;
+    }
+  } // namespace
+
+  void
+  pair_plan(const DevGrid &g, const int n_cu, int out[6])
+  {
+    const PairTiling tl = make_pair_tiling(g, n_cu);
+    out[0]              = tl.ntx;
+    out[1]              = tl.nty;
+    out[2]              = tl.nzc;
+    out[3]              = tl.zlen;
+    out[4]              = tl.x_first;
+    out[5]              = tl.y_first;
+  }
+
+  bool
+  pair_sweep(const DevGrid &g, const DevKron &k, const TiledArgs &a, hipStream_t st)
+  {
+    if (g.p != P || !k.valid || a.phase != 0)
+      return false;
+    // 32-bit byte offsets inside a DoF plane
+    if (g.stride[2] * 8 >= (1ll << 31))
+      return false;
+    const PairTiling tl = make_pair_tiling(g, a.n_cu);
+    switch (a.mode)
+      {
+        case OP_PLAIN: return launch_pair<OP_PLAIN>(g, k, a, tl, st);
+        case OP_RESIDUAL: return launch_pair<OP_RESIDUAL>(g, k, a, tl, st);
+        case PC_PLAIN: return launch_pair<PC_PLAIN>(g, k, a, tl, st);
+        case PC_FIRST: return launch_pair<PC_FIRST>(g, k, a, tl, st);
+        case PC_STEP1: return launch_pair<PC_STEP1>(g, k, a, tl, st);
+        case PC_UPDATE: return launch_pair<PC_UPDATE>(g, k, a, tl, st);
+        default: return false;
+      }
+  }
+} // namespace asmamd
