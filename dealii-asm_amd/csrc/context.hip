@@ -78,6 +78,7 @@ struct asm_ctx
   // wave-pair sweeps (kernels_pair.hip) of a tiled context on a tensor-product mesh: tables of A and of P (valid = 0: the
   // tiled kernels take the sweep); ASM_PAIR=0 switches them off
   DevKron                  kron_a{}, kron_p{};
+  const int *              order_pair = nullptr; // work order of the wave-pair sweeps (pair_order)
   std::vector<void *>      allocs;
   bool                     ras_direct = true; // ASM_RAS_ATOMICS: restricted additive Schwarz through the atomics path on one rank too
   std::vector<double *>    work_pool; // released solver work vectors (asm_work_vector_*), kept until asm_destroy
@@ -613,6 +614,7 @@ namespace
     a.n_cu   = ctx->n_cu;
     a.rows   = ctx->laplace_rows;
     a.order  = (a.mode == OP_PLAIN || a.mode == OP_RESIDUAL) ? ctx->order_a : ctx->order_p;
+    a.pair_order = ctx->order_pair;
     if (!ov && ctx->debug_two_phase)
       {
         a.phase = 1;
@@ -1429,7 +1431,8 @@ asm_create(const asm_params *p, asm_ctx **out)
       UP(hk.sym, &dk.sym);
       UP(hk.mat, &dk.mat);
       UP(hk.diag, &dk.diag);
-      dk.valid = 1;
+      dk.mask_constrained = hk.mask_constrained ? 1 : 0;
+      dk.valid            = 1;
       return ASM_OK;
     };
     HostKron hk;
@@ -1737,6 +1740,13 @@ asm_create(const asm_params *p, asm_ctx **out)
   // single-phase tiled sweeps: the workgroups at Dirichlet faces first (kernels.h: tiled_order); ASM_NO_TILED_ORDER keeps
   // the launch positions (experiments)
   // (tune_tiled_laplace has set the tables of a context that measures its candidates; the others:)
+  if ((ctx->kron_a.valid || ctx->kron_p.valid) && std::getenv("ASM_NO_TILED_ORDER") == nullptr)
+    {
+      std::vector<int> order;
+      pair_order(ctx->g, ctx->n_cu, order);
+      if ((err = upload(ctx, order, &ctx->order_pair)))
+        return fail(err);
+    }
   if ((ctx->s.laplace_tiled || ctx->s.fdm_tiled) && std::getenv("ASM_NO_TILED_ORDER") == nullptr && ctx->order_p == nullptr)
     {
       std::vector<int> order;

@@ -133,6 +133,7 @@ namespace asmamd
   struct DevKron
   {
     int           valid;
+    int           mask_constrained; // 1: constrained (Dirichlet) DoFs of the source are read as zero (Laplace operator)
     int           n_cls[3];
     const int *   cls[3]; // [nc[d] + 2]: class of cell c at [c + 1]
     const int *   sym;    // [3][KRON_MAX_CLS] 1: the columns 0..2 of F and B are even, 3..4 odd vectors

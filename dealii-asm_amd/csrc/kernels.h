@@ -78,6 +78,8 @@ namespace asmamd
     int rows = 0;
     // single-phase launches: work index of every launch position (tiled_order), or nullptr = the positions themselves
     const int *order = nullptr;
+    // the same for the wave-pair sweep (pair_order)
+    const int *pair_order = nullptr;
   };
   // Work order of a single-phase tiled sweep (device-independent, host side).  The workgroups at Dirichlet faces live
   // up to 1.5 times as long as the others (constrained rows, full-matrix sweeps; profiles/r03_workgroup_trace.txt), and a
@@ -96,6 +98,10 @@ namespace asmamd
   //      tables k with the fused update of a.mode; single-phase launches only (false: not applicable, nothing launched).
   //      Constrained DoFs are neither read nor written: the caller sets them (vec_constrained / vec_constrained_fused).
   bool pair_sweep(const DevGrid &g, const DevKron &k, const TiledArgs &a, hipStream_t st);
+  // work order of the pair sweep (host side, device-independent): order[p] = work index (tile x fastest, tile y, z chunk)
+  // of launch position p: every XCD keeps its contiguous range of the work but starts with its expensive workgroups (tiles
+  // at physical boundaries).  Returns the number of workgroups.
+  int pair_order(const DevGrid &g, int n_cu, std::vector<int> &order);
   // the tiling of the pair sweep (host side): out = {tiles x, tiles y, z chunks, layers per chunk, first cell x, first cell y}
   void pair_plan(const DevGrid &g, int n_cu, int out[6]);
 

@@ -32,7 +32,11 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <functional>
+#include <map>
+#include <mutex>
 #include <utility>
+#include <vector>
 
 namespace asmamd
 {
@@ -189,6 +193,8 @@ namespace asmamd
       lds_cptr      mx, my;
       int           clx, cly;
       bool          nsx, nsy, any_nsx, any_nsy;
+      bool          dup; // the unmasked copy of the even-odd sweep for waves without such lanes (not in the three-term kernel:
+                         // it costs the compiler registers that kernel does not have to spare)
       const double *gx, *gy; // the tables of the x / y classes in global memory: [class][KRON_MAT_STRIDE]
     };
     // one sweep direction of a plane
@@ -197,16 +203,27 @@ namespace asmamd
     sweep_dir(double (&v)[NE], const XYMatrices &m)
     {
       const bool ns = XDIR ? m.nsx : m.nsy;
-      if (!ns)
+      if (m.dup && !(XDIR ? m.any_nsx : m.any_nsy))
         {
+          // (the common case, wave-uniform: no lane masks, no copies at a join)
           const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 50 : 66));
           if (XDIR)
             sweep_x<FWD>(v, q);
           else
             sweep_y<FWD>(v, q);
         }
-      if (XDIR ? m.any_nsx : m.any_nsy)
+      else
         {
+          if (!ns)
+            {
+              const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 50 : 66));
+              if (XDIR)
+                sweep_x<FWD>(v, q);
+              else
+                sweep_y<FWD>(v, q);
+            }
+          if (!(XDIR ? m.any_nsx : m.any_nsy))
+            return;
           // (wave-uniform loop over the classes without an even-odd form that occur in the wave: none, or one)
           const int          cls  = XDIR ? m.clx : m.cly;
           unsigned long long todo = __ballot(ns);
@@ -245,20 +262,28 @@ namespace asmamd
 
     // ---------------------------------------------------------------------------------------------------------------
     // The next layer's source planes and update operands wait in FIXED accumulation registers which the compiler never
-    // sees; it takes a0.. upwards if it has to spill (audit: its v_accvgpr_* stay below a28, no scratch):
+    // sees; it takes a0.. upwards if it has to spill (audit: its v_accvgpr_* stay below A_BASE, no scratch):
     //   a[A_S0 .. +49], a[A_S1 .. +49]   the two source planes of this wave: row j at +10 j: x 0..1, x 2..3, x 4
     //   a[A_XA0 .. +31], a[A_XA1 .. +31] first update operand of its two output planes: row j at +8 j
-    //   a[A_XB0 .. +31], a[A_XB1 .. +31] second update operand (three-term update); the prologue's plane 0 (50 registers)
+    //   a[A_XB0 .. +31], a[A_XB1 .. +31] second update operand (three-term update only)
+    //   a[A_P0 .. +49]                   the prologue's plane 0: the registers of the operands requested after it
+    // The three-term update leaves the compiler a0..a27, the other modes a0..a91.
     // ---------------------------------------------------------------------------------------------------------------
-    constexpr int A_S0 = 28, A_S1 = 78, A_XA0 = 128, A_XA1 = 160, A_XB0 = 192, A_XB1 = 224, A_P0 = 192;
-    static_assert(A_XB1 + 32 == 256 && A_P0 + 50 <= 256, "accumulation register map");
+    template <bool NEED_B>
+    struct ARegs
+    {
+      static constexpr int BASE = NEED_B ? 28 : 92;
+      static constexpr int S0 = BASE, S1 = BASE + 50, XA0 = BASE + 100, XA1 = BASE + 132, XB0 = NEED_B ? BASE + 164 : 0, XB1 = NEED_B ? BASE + 196 : 0;
+      static constexpr int P0 = NEED_B ? XB0 : XA0;
+      static_assert((NEED_B ? XB1 : XA1) + 32 == 256 && P0 + 50 <= 256, "accumulation register map");
+    };
 #define ASM_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+    // (makes the kernel's register count cover the fixed registers; the statement itself does nothing)
     __device__ __forceinline__ void
     areg_reserve()
     {
-      asm volatile("" ::: "a28", "a29", ASM_A10(3), ASM_A10(4), ASM_A10(5), ASM_A10(6), ASM_A10(7), ASM_A10(8), ASM_A10(9), ASM_A10(10), ASM_A10(11),
-                   ASM_A10(12), ASM_A10(13), ASM_A10(14), ASM_A10(15), ASM_A10(16), ASM_A10(17), ASM_A10(18), ASM_A10(19), ASM_A10(20), ASM_A10(21),
-                   ASM_A10(22), ASM_A10(23), ASM_A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
+      asm volatile("" ::: ASM_A10(10), ASM_A10(11), ASM_A10(12), ASM_A10(13), ASM_A10(14), ASM_A10(15), ASM_A10(16), ASM_A10(17), ASM_A10(18),
+                   ASM_A10(19), ASM_A10(20), ASM_A10(21), ASM_A10(22), ASM_A10(23), ASM_A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
     }
 #undef ASM_A10
 
@@ -322,6 +347,7 @@ namespace asmamd
       bool ph_x, ph_y;        // ... of which only column 0 / row 0 exist
       bool xd0, yd0;          // column 0 / row 0 is a Dirichlet plane: not stored
       bool left_ok, below_ok; // the lane to the left / below belongs to the tile
+      unsigned smask;         // source DoFs read as zero: bit 0 / 1: column 0 / 4, bit 2 / 3: row 0 / 4 (Laplace operator at Dirichlet faces)
       unsigned srow8[N1];     // source: byte offset of DoF row j of the cell inside a plane (cells not computed: cell 0)
       unsigned sd4;           // ... and the step from column 0 to column 4 (periodic seam), bytes
       unsigned orow8[P];      // operands / dst: byte offset of DoF row j of the DoFs the lane owns
@@ -345,6 +371,27 @@ namespace asmamd
       operand_request_row<A0, 1>(plane, c.orow8[1]);
       operand_request_row<A0, 2>(plane, c.orow8[2]);
       operand_request_row<A0, 3>(plane, c.orow8[3]);
+    }
+
+    // constrained DoFs of a source plane read as zero (whole plane: a Dirichlet plane in z)
+    __device__ __forceinline__ void
+    mask_source(double (&v)[NE], const Lane &c, const bool plane_constrained)
+    {
+      if (plane_constrained)
+        {
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            v[e] = 0.;
+        }
+      else if (c.smask != 0u)
+        {
+#pragma unroll
+          for (int j = 0; j < N1; ++j)
+#pragma unroll
+            for (int i = 0; i < N1; ++i)
+              if ((i == 0 && (c.smask & 1u)) || (i == 4 && (c.smask & 2u)) || (j == 0 && (c.smask & 4u)) || (j == 4 && (c.smask & 8u)))
+                v[j * 5 + i] = 0.;
+        }
     }
 
     template <int MODE>
@@ -456,16 +503,41 @@ namespace asmamd
       return g.store_index_near(2, K) * g.stride[2];
     }
 
+#ifdef ASM_PAIR_STAMP
+    // diagnostic build: cycles (s_memtime) one interior wave spends per stage, summed over its layers
+    __device__ unsigned long long g_pair_stamps[16];
+#  define PSTAMP(i)                                                    \
+    do                                                                 \
+      {                                                                \
+        if (stamp_on)                                                  \
+          {                                                            \
+            const unsigned long long t = __builtin_amdgcn_s_memtime(); \
+            stamp_acc[i] += t - stamp_t;                               \
+            stamp_t = t;                                               \
+          }                                                            \
+      }                                                                \
+    while (0)
+#else
+#  define PSTAMP(i)
+#endif
+
     // ---------------------------------------------------------------------------------------------------------------
     template <int MODE>
     __global__ void __launch_bounds__(128) pair_sweep_kernel(const DevGrid g, const DevKron kr, const TiledArgs a, const PairTiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
       using MT = ModeTraits<MODE>;
+      using AR = ARegs<MT::need_b>;
       // workgroups b and b + 8 land on the same XCD: contiguous ranges of the work per XCD (L2 locality of neighbouring tiles)
-      const int wi = (int)xcd_block(blockIdx.x, gridDim.x);
+      int wi = (int)xcd_block(blockIdx.x, gridDim.x);
+      if (a.pair_order != nullptr) // expensive workgroups first (pair_order); a scalar load
+        wi = ((const __attribute__((address_space(4))) int *)a.pair_order)[wi];
       const int tx = wi % tl.ntx, ty = (wi / tl.ntx) % tl.nty, zc = wi / (tl.ntx * tl.nty);
       const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
+#ifdef ASM_PAIR_STAMP
+      const bool         stamp_on = tx == tl.ntx / 2 && ty == tl.nty / 2 && zc == tl.nzc / 2 && threadIdx.x < 64;
+      unsigned long long stamp_t = __builtin_amdgcn_s_memtime(), stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
       const int lane = threadIdx.x & 63, cl = lane % TX, rw = lane / TX;
       const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 / 1, wave-uniform
@@ -485,6 +557,10 @@ namespace asmamd
         c.below_ok       = rw >= 1;
         c.xd0            = c.owner && g.dirichlet(0, P * cx);
         c.yd0            = c.owner && g.dirichlet(1, P * cy);
+        c.smask          = 0u;
+        if (kr.mask_constrained && c.cell_xy)
+          c.smask = (g.dirichlet(0, P * cx) ? 1u : 0u) | (g.dirichlet(0, P * cx + P) ? 2u : 0u) | (g.dirichlet(1, P * cy) ? 4u : 0u) |
+                    (g.dirichlet(1, P * cy + P) ? 8u : 0u);
         // source rows: the cell itself, or cell (0, 0) for lanes without a computed cell (any finite data: zero diagonal)
         const int sx = c.cell_xy ? cx : 0, sy = c.cell_xy ? cy : 0;
         const int x0 = g.store_index_near(0, P * sx);
@@ -522,6 +598,7 @@ namespace asmamd
       mxy.nsy     = c.cell_xy && kr.sym[1 * KRON_MAX_CLS + cly] == 0;
       mxy.any_nsx = __any(mxy.nsx);
       mxy.any_nsy = __any(mxy.nsy);
+      mxy.dup     = !MT::need_b;
       mxy.gx      = kr.mat + 0 * KRON_MAX_CLS * KRON_MAT_STRIDE;
       mxy.gy      = kr.mat + 1 * KRON_MAX_CLS * KRON_MAT_STRIDE;
       // this lane's diagonal: column e of this wave at Dz + 5 e (cells that are not computed: zeros)
@@ -550,21 +627,24 @@ namespace asmamd
       // ---- prologue: plane 0 of the first layer (wave 0 transforms it, both pick their columns), first requests
       {
         const long long z0 = plane_offset(g, P * z_first);
-        plane_request<A_P0>(a.src + z0, c);
-        plane_request<A_S0>(a.src + plane_offset(g, P * z_first + kf), c);
-        plane_request<A_S1>(a.src + plane_offset(g, P * z_first + kf + 1), c);
-        if (MT::need_a && z_first >= Zb)
-          {
-            operand_request<A_XA0>(opA + plane_offset(g, P * z_first + kb), c);
-            operand_request<A_XA1>(opA + plane_offset(g, P * z_first + kb + 1), c);
-          }
+        plane_request<AR::P0>(a.src + z0, c);
+        plane_request<AR::S0>(a.src + plane_offset(g, P * z_first + kf), c);
+        plane_request<AR::S1>(a.src + plane_offset(g, P * z_first + kf + 1), c);
         vm_wait<0>();
         double v[NE];
-        plane_unpack<A_P0>(v);
+        plane_unpack<AR::P0>(v);
+        if (kr.mask_constrained)
+          mask_source(v, c, g.dirichlet(2, P * z_first));
+        // (the first operands go into registers the prologue's plane occupied)
+        if (MT::need_a && z_first >= Zb)
+          {
+            operand_request<AR::XA0>(opA + plane_offset(g, P * z_first + kb), c);
+            operand_request<AR::XA1>(opA + plane_offset(g, P * z_first + kb + 1), c);
+          }
         if (MT::need_b && z_first >= Zb)
           {
-            operand_request<A_XB0>(a.x_old + plane_offset(g, P * z_first + kb), c);
-            operand_request<A_XB1>(a.x_old + plane_offset(g, P * z_first + kb + 1), c);
+            operand_request<AR::XB0>(a.x_old + plane_offset(g, P * z_first + kb), c);
+            operand_request<AR::XB1>(a.x_old + plane_offset(g, P * z_first + kb + 1), c);
           }
         plane2d<true>(v, mxy);
         if (role == 0)
@@ -583,6 +663,7 @@ namespace asmamd
       for (int cz = z_first; cz < Ze; ++cz)
         {
           const bool emit = cz >= Zb, more = cz + 1 < Ze;
+          PSTAMP(0);
           // the diagonals of this layer's z class
           const int clz = uniform_load(kr.cls[2], cz + 1);
           if (clz != clz_cached)
@@ -601,7 +682,9 @@ namespace asmamd
               vm_wait<MT::n_operand_requests>(); // younger than the plane requests: the operand requests of this layer
             {
               double v[NE];
-              plane_unpack<A_S0>(v);
+              plane_unpack<AR::S0>(v);
+              if (kr.mask_constrained)
+                mask_source(v, c, false); // (planes 1..3 of a layer are never Dirichlet planes)
               plane2d<true>(v, mxy);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
@@ -609,7 +692,9 @@ namespace asmamd
             }
             {
               double v[NE];
-              plane_unpack<A_S1>(v);
+              plane_unpack<AR::S1>(v);
+              if (kr.mask_constrained)
+                mask_source(v, c, g.dirichlet(2, P * cz + kf + 1));
               plane2d<true>(v, mxy);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
@@ -618,13 +703,15 @@ namespace asmamd
             // the next layer's planes: a whole layer ahead
             if (more)
               {
-                plane_request<A_S0>(a.src + plane_offset(g, P * (cz + 1) + kf), c);
-                plane_request<A_S1>(a.src + plane_offset(g, P * (cz + 1) + kf + 1), c);
+                plane_request<AR::S0>(a.src + plane_offset(g, P * (cz + 1) + kf), c);
+                plane_request<AR::S1>(a.src + plane_offset(g, P * (cz + 1) + kf + 1), c);
               }
           }
           const lds_cptr      mz    = Ml + (2 * KRON_MAX_CLS + clz) * KRON_MAT_STRIDE;
           const bool          eo_z  = uniform_load(kr.sym, 2 * KRON_MAX_CLS + clz) != 0;
+          PSTAMP(1);
           __syncthreads();
+          PSTAMP(2);
           // ---- z sweeps of this wave's columns and the diagonal, in place in the scratchpad; reads run one column ahead
           {
             double n1 = X_z[(0 * NE) * 64], n2 = X_z[(1 * NE) * 64], n3 = X_z[(2 * NE) * 64], n4 = X_z[(3 * NE) * 64];
@@ -676,7 +763,9 @@ namespace asmamd
                 columns(FullCoef(gz), FullCoef(gz + 25));
               }
           }
+          PSTAMP(3);
           __syncthreads();
+          PSTAMP(4);
           if (emit)
             {
               // ---- backward x-y transforms of this wave's two output planes, merge, update, store
@@ -691,13 +780,13 @@ namespace asmamd
               else
                 vm_wait<30>(); // younger than the operand requests: the 30 plane requests of this layer
               plane2d<false>(w, mxy);
-              emit_plane<MODE, A_XA0, A_XB0>(a, c, a.dst + zo0, w, con0);
+              emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo0, w, con0);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 w[e] = X_bwd[(1 * NE + e) * 64];
               __syncthreads(); // the scratchpad may take the next layer's planes
               plane2d<false>(w, mxy);
-              emit_plane<MODE, A_XA1, A_XB1>(a, c, a.dst + zo1, w, false);
+              emit_plane<MODE, AR::XA1, AR::XB1>(a, c, a.dst + zo1, w, false);
             }
           else
             __syncthreads();
@@ -706,16 +795,25 @@ namespace asmamd
               // the next layer's update operands
               if (MT::need_a)
                 {
-                  operand_request<A_XA0>(opA + plane_offset(g, P * (cz + 1) + kb), c);
-                  operand_request<A_XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                  operand_request<AR::XA0>(opA + plane_offset(g, P * (cz + 1) + kb), c);
+                  operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
                 }
               if (MT::need_b)
                 {
-                  operand_request<A_XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
-                  operand_request<A_XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                  operand_request<AR::XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
+                  operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
                 }
             }
         }
+#ifdef ASM_PAIR_STAMP
+      PSTAMP(5);
+      if (stamp_on && lane == 0)
+        {
+          for (int i = 0; i < 8; ++i)
+            atomicAdd(&g_pair_stamps[i], stamp_acc[i]);
+          atomicAdd(&g_pair_stamps[8], (unsigned long long)(Ze - z_first));
+        }
+#endif
       if (Ze == g.nc[2] && has_phantom(g, 2))
         {
           // top plane of the block: what the last layer left in the carries of both waves, transformed back by wave 0
@@ -733,20 +831,103 @@ namespace asmamd
                 v[e] = Xl[e * 64];
               const long long zo = plane_offset(g, P * g.nc[2]);
               if (MT::need_a)
-                operand_request<A_XA0>(opA + zo, c);
+                operand_request<AR::XA0>(opA + zo, c);
               if (MT::need_b)
-                operand_request<A_XB0>(a.x_old + zo, c);
+                operand_request<AR::XB0>(a.x_old + zo, c);
               vm_wait<0>();
               plane2d<false>(v, mxy);
-              emit_plane<MODE, A_XA0, A_XB0>(a, c, a.dst + zo, v, false);
+              emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo, v, false);
             }
         }
     }
 
     // ---- host side ------------------------------------------------------------------------------------------------
+    // relative cost of a workgroup's layer: tiles with cells at a physical boundary redo the sweeps of that direction
+    // with the full matrices under lane masks (stage timers: profiles/r04_pair_stamps.txt)
+    double
+    tile_cost(const DevGrid &g, const PairTiling &tl, const int tx, const int ty)
+    {
+      const auto at_boundary = [&](const int d, const int c0) {
+        // cells c0 .. c0 + 7 of direction d; the first / last cell of a block at a physical boundary
+        const bool lo = !g.wrap[d] && g.ext_lo[d] == 0, hi = !g.wrap[d] && g.own_hi[d] == g.nc[d] * P;
+        return (lo && c0 <= 0) || (hi && c0 <= g.nc[d] - 1 && c0 + TX > g.nc[d] - 1);
+      };
+      return 1.0 + (at_boundary(0, tx * OX + tl.x_first) ? 0.4 : 0.) + (at_boundary(1, ty * OY + tl.y_first) ? 0.4 : 0.);
+    }
+    int
+    chunk_layers(const DevGrid &g, const PairTiling &tl, const int zc)
+    {
+      const int  Zb = zc * tl.zlen, Ze = std::min(Zb + tl.zlen, g.nc[2]);
+      const bool halo = Zb > 0 || g.wrap[2] || g.ext_lo[2] < 0;
+      return Ze - Zb + (halo ? 1 : 0);
+    }
+    // launch position -> work index (tile x fastest, tile y, z chunk): every XCD (workgroups b, b + 8, ...) keeps a
+    // contiguous range of the work - neighbouring tiles share cache lines in its L2 - but takes its expensive workgroups
+    // first; returns the time the last workgroup ends (in layer times) when `slots` workgroups run at a time
+    double
+    schedule(const DevGrid &g, const PairTiling &tl, const long long slots, std::vector<int> *order)
+    {
+      const int           n = tl.ntx * tl.nty * tl.nzc;
+      std::vector<double> cost(n);
+      for (int w = 0; w < n; ++w)
+        cost[w] = tile_cost(g, tl, w % tl.ntx, (w / tl.ntx) % tl.nty) * (chunk_layers(g, tl, w / (tl.ntx * tl.nty)) + 0.5);
+      std::vector<int> pos(n);
+      for (int xcd = 0; xcd < 8; ++xcd)
+        {
+          const int begin = xcd * (n >> 3) + std::min(xcd, n & 7), count = (n >> 3) + (xcd < (n & 7) ? 1 : 0);
+          std::vector<int> w(count);
+          for (int i = 0; i < count; ++i)
+            w[i] = begin + i;
+          std::stable_sort(w.begin(), w.end(), [&](const int x, const int y) { return cost[x] > cost[y]; });
+          for (int i = 0; i < count; ++i)
+            pos[begin + i] = w[i];
+        }
+      if (order != nullptr)
+        *order = pos;
+      // list scheduling in dispatch order: block b takes launch position xcd_block(b)
+      std::vector<double> free_at((size_t)std::max<long long>(1, std::min<long long>(slots, n)), 0.);
+      std::make_heap(free_at.begin(), free_at.end(), std::greater<double>());
+      double end = 0.;
+      for (int bb = 0; bb < n; ++bb)
+        {
+          std::pop_heap(free_at.begin(), free_at.end(), std::greater<double>());
+          const double t = free_at.back() + cost[pos[(int)xcd_block(bb, n)]];
+          free_at.back() = t;
+          std::push_heap(free_at.begin(), free_at.end(), std::greater<double>());
+          end = std::max(end, t);
+        }
+      return end;
+    }
+
     PairTiling
     make_pair_tiling(const DevGrid &g, const int n_cu_in)
     {
+      // (a pure function of the block and the device: computed once per shape)
+      struct Key
+      {
+        int v[17];
+        bool operator<(const Key &o) const { return std::lexicographical_compare(v, v + 17, o.v, o.v + 17); }
+      };
+      static std::mutex                mtx;
+      static std::map<Key, PairTiling> cache;
+      Key                              key;
+      for (int d = 0; d < 3; ++d)
+        {
+          key.v[d]      = g.nc[d];
+          key.v[3 + d]  = g.wrap[d];
+          key.v[6 + d]  = g.ext_lo[d];
+          key.v[9 + d]  = g.own_hi[d];
+          key.v[12 + d] = g.ext_hi[d];
+        }
+      const char *env = std::getenv("ASM_PAIR_ZCHUNKS");
+      key.v[15]       = n_cu_in;
+      key.v[16]       = env != nullptr ? std::atoi(env) : 0;
+      {
+        std::lock_guard<std::mutex> lock(mtx);
+        const auto                  it = cache.find(key);
+        if (it != cache.end())
+          return it->second;
+      }
       PairTiling tl;
       const int  n_cu  = n_cu_in > 0 ? n_cu_in : 256;
       const auto first = [&](const int d) { return (g.wrap[d] || g.ext_lo[d] < 0) ? -1 : 0; };
@@ -762,31 +943,35 @@ namespace asmamd
       tl.y_first = first(1);
       tl.ntx     = tiles(0, tl.x_first, OX);
       tl.nty     = tiles(1, tl.y_first, OY);
-      // z chunks: two workgroups per compute unit run at a time; a chunk costs its layers plus the halo layer below it.
-      // Fewest rounds x layers; ties: fewer chunks (fewer halo layers)
-      const long long slots  = 2ll * n_cu, tiles_xy = (long long)tl.ntx * tl.nty;
-      const bool      halo_z = g.wrap[2] || g.ext_lo[2] < 0;
+      // z chunks: two workgroups per compute unit run at a time; a chunk costs its layers plus the halo layer below it,
+      // tiles at physical boundaries cost more per layer: the chunk count whose simulated schedule ends first
+      const long long slots = 2ll * n_cu;
       int             best = 1;
-      double          best_cost = 1e300;
-      if (const char *e = std::getenv("ASM_PAIR_ZCHUNKS"))
-        best = std::max(1, std::min(std::atoi(e), g.nc[2]));
+      if (key.v[16] > 0)
+        best = std::max(1, std::min(key.v[16], g.nc[2]));
       else
-        for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
-          {
-            const int       zlen   = (g.nc[2] + nzc - 1) / nzc;
-            const int       chunks = (g.nc[2] + zlen - 1) / zlen;
-            const long long wgs    = tiles_xy * chunks;
-            const double    rounds = (double)((wgs + slots - 1) / slots);
-            // (average of whole and fractional rounds: compute units take new workgroups as they fall free)
-            const double cost = 0.5 * (rounds + (double)wgs / slots) * (zlen + ((chunks > 1 || halo_z) ? 1.0 : 0.0) + 0.5);
-            if (cost < best_cost - 1e-9)
-              {
-                best_cost = cost;
-                best      = chunks;
-              }
-          }
+        {
+          double best_end = 1e300;
+          int    last_chunks = 0;
+          for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
+            {
+              tl.zlen = (g.nc[2] + nzc - 1) / nzc;
+              tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
+              if (tl.nzc == last_chunks || (long long)tl.ntx * tl.nty * tl.nzc > 16384)
+                continue;
+              last_chunks      = tl.nzc;
+              const double end = schedule(g, tl, slots, nullptr);
+              if (end < best_end * (1. - 1e-9))
+                {
+                  best_end = end;
+                  best     = tl.nzc;
+                }
+            }
+        }
       tl.zlen = (g.nc[2] + best - 1) / best;
       tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
+      std::lock_guard<std::mutex> lock(mtx);
+      cache[key] = tl;
       return tl;
     }
 
@@ -810,6 +995,29 @@ namespace asmamd
       return true;
     }
   } // namespace
+
+#ifdef ASM_PAIR_STAMP
+  // stage cycles of the diagnostic build (tools/pair_stamps.py); not part of the C ABI
+  extern "C" void
+  asm_debug_pair_stamps(unsigned long long out[16], int reset)
+  {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stamps), 16 * sizeof(unsigned long long));
+    if (reset)
+      {
+        unsigned long long z[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), z, sizeof(z));
+      }
+  }
+#endif
+
+  int
+  pair_order(const DevGrid &g, const int n_cu, std::vector<int> &order)
+  {
+    const PairTiling tl = make_pair_tiling(g, n_cu);
+    schedule(g, tl, 2ll * (n_cu > 0 ? n_cu : 256), &order);
+    return (int)order.size();
+  }
 
   void
   pair_plan(const DevGrid &g, const int n_cu, int out[6])

@@ -17,6 +17,7 @@ namespace asmamd
   struct HostKron
   {
     bool                valid = false;
+    bool                mask_constrained = false; // the sweep reads constrained DoFs of the source as zero
     int                 n_cls[3] = {0, 0, 0};
     std::vector<int>    cls[3]; // [nc + 2]
     std::vector<int>    sym;    // [3][KRON_MAX_CLS]
@@ -64,7 +65,8 @@ namespace asmamd
     inline void
     init(HostKron &k)
     {
-      k.valid = false;
+      k.valid            = false;
+      k.mask_constrained = false;
       k.sym.assign(3 * KRON_MAX_CLS, 0);
       k.mat.assign((size_t)3 * KRON_MAX_CLS * KRON_MAT_STRIDE, 0.);
       k.diag.assign((size_t)KRON_MAX_CLS * KRON_MAX_CLS * KRON_MAX_CLS * KRON_DIAG_STRIDE, 0.);
@@ -138,18 +140,19 @@ namespace asmamd
     return true;
   }
 
-  // Laplace operator, degree 4, box cells of one size per direction; constrained DoFs read as zero
+  // Laplace operator, degree 4, box cells of one size per direction: ONE class per direction (F = B = F_ref, even / odd
+  // columns); the sweep zeroes the constrained DoFs of the source itself (DevKron::mask_constrained), so that cells at a
+  // Dirichlet face need no matrices of their own - and no sweeps with full matrices
   inline bool
   build_kron_laplace(const HostSetup &s, const Basis1D &b, HostKron &k)
   {
     using namespace kron_detail;
     init(k);
-    if (s.g.p != 4 || !s.cartesian || b.F_ref.size() != 25 || b.lam_ref.size() != 5)
+    if (s.g.p != 4 || !s.cartesian || b.F_ref.size() != 25 || b.lam_ref.size() != 5 || !parity_sorted(b.F_ref.data()))
       return false;
     double h[3] = {0., 0., 0.};
     for (int d = 0; d < 3; ++d)
       {
-        std::map<int, int> ids; // mask bits -> class
         k.cls[d].assign(s.ence[d], 0);
         for (int c = -1; c <= s.g.nc[d]; ++c)
           {
@@ -159,41 +162,19 @@ namespace asmamd
               h[d] = s.h[d][c + 1];
             else if (h[d] != s.h[d][c + 1])
               return false; // graded mesh: several diagonals per direction (tiled kernel)
-            const int  bits = (s.g.dirichlet(d, 4 * c) ? 1 : 0) | (s.g.dirichlet(d, 4 * c + 4) ? 2 : 0);
-            const auto it   = ids.emplace(bits, (int)ids.size());
-            if (it.second)
-              {
-                const int id = it.first->second;
-                if (id >= KRON_MAX_CLS)
-                  return false;
-                double F[25], B[25];
-                for (int i = 0; i < 5; ++i)
-                  for (int a = 0; a < 5; ++a)
-                    {
-                      const bool con = (i == 0 && (bits & 1)) || (i == 4 && (bits & 2));
-                      F[i * 5 + a]   = con ? 0. : b.F_ref[i * 5 + a];
-                      B[i * 5 + a]   = b.F_ref[i * 5 + a];
-                    }
-                store_matrices(k, d, id, F, B, bits == 0 && parity_sorted(b.F_ref.data()));
-              }
-            k.cls[d][c + 1] = it.first->second;
           }
-        k.n_cls[d] = (int)ids.size();
+        store_matrices(k, d, 0, b.F_ref.data(), b.F_ref.data(), true);
+        k.n_cls[d] = 1;
       }
-    // one cell size per direction: one diagonal for all class triples
-    // (hy hz / hx la + hx hz / hy lb + hx hy / hz lc, kernels_tiled.hip: laplace_cart_tiled_kernel)
+    // hy hz / hx la + hx hz / hy lb + hx hy / hz lc (kernels_tiled.hip: laplace_cart_tiled_kernel)
     const double alpha = h[1] / h[0] * h[2], beta = h[0] / h[1] * h[2], gamma = h[0] * h[1] / h[2];
-    for (int cz = 0; cz < k.n_cls[2]; ++cz)
-      for (int cy = 0; cy < k.n_cls[1]; ++cy)
-        for (int cx = 0; cx < k.n_cls[0]; ++cx)
-          {
-            double *D = &k.diag[(size_t)((cz * KRON_MAX_CLS + cy) * KRON_MAX_CLS + cx) * KRON_DIAG_STRIDE];
-            for (int c = 0; c < 5; ++c)
-              for (int bb = 0; bb < 5; ++bb)
-                for (int a = 0; a < 5; ++a)
-                  D[(bb * 5 + a) * 5 + c] = std::fma(alpha, b.lam_ref[a], std::fma(beta, b.lam_ref[bb], gamma * b.lam_ref[c]));
-          }
-    k.valid = true;
+    double *     D = &k.diag[0];
+    for (int c = 0; c < 5; ++c)
+      for (int bb = 0; bb < 5; ++bb)
+        for (int a = 0; a < 5; ++a)
+          D[(bb * 5 + a) * 5 + c] = std::fma(alpha, b.lam_ref[a], std::fma(beta, b.lam_ref[bb], gamma * b.lam_ref[c]));
+    k.mask_constrained = true;
+    k.valid            = true;
     return true;
   }
 } // namespace asmamd
