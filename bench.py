@@ -317,7 +317,9 @@ def main():
                 traffic, traffic_src = tr[key][dom], tr[key]["source"]
         except OSError:
             pass
-        lap_variant = "generic" if args.workload == "kershaw" else ctx.kernel_variant()
+        pair_a, pair_p = ctx.pair_sweeps()
+        lap_variant = "generic" if args.workload == "kershaw" else ("wave-pair" if pair_a else ctx.kernel_variant())
+        fdm_variant = "wave-pair" if pair_p else ctx.kernel_variant()
         # the deformed-cell Laplace sweep is bound by fp64 issue, not by memory (report the FLOP rate then)
         fp64_bound = args.workload == "kershaw" and dom == "laplace"
         if fp64_bound:
@@ -325,7 +327,7 @@ def main():
             kernels["laplace"]["TFLOPps"] = flops / (kernels["laplace"]["avg_ms"] * 1e-3) / 1e12
         roofline = {
             "bound": "fp64" if fp64_bound else "hbm",
-            "kernel": {"laplace": f"Laplace sweep ({lap_variant})", "fdm": f"FDM Schwarz sweep ({ctx.kernel_variant()})"}[dom],
+            "kernel": {"laplace": f"Laplace sweep ({lap_variant})", "fdm": f"FDM Schwarz sweep ({fdm_variant})"}[dom],
             "achieved": kernels[dom]["GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -366,6 +368,7 @@ def main():
                 "proc_grid": grid,
                 "kernel_variant": ctx.kernel_variant(),
                 "laplace_rows": ctx.tiled_laplace_rows(),
+                "pair_sweeps": {"laplace": pair_a, "fdm": pair_p},
                 "lambda_max_estimate": lam,
                 **({"rehearsal": "periodic directions closed by RCCL messages of the rank to itself"} if self_interface else {}),
             },
@@ -406,7 +409,8 @@ def main():
                             "hbm_frac": 24.0 * ns.n_owned / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["north_star_point"] = {"cells": list(NORTH_STAR_CELLS), "n_dofs": ns.n_dofs, "steps": ns_steps,
                                        "ms_per_step": el / ns_steps * 1e3, "value": ns.n_dofs * ns_steps / el, "unit": "DoF/s",
-                                       "laplace_rows": ns.tiled_laplace_rows(), "kernels": nk}
+                                       "laplace_rows": ns.tiled_laplace_rows(),
+                                       "pair_sweeps": dict(zip(("laplace", "fdm"), ns.pair_sweeps())), "kernels": nk}
             ns.close()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, pkg, cells)

@@ -208,6 +208,8 @@ EXPORTED_SYMBOLS = [
     "asm_mg_restrict",
     "asm_mg_vmult",
     "asm_tiled_plan",
+    "asm_pair_plan",
+    "asm_pair_sweeps_in_use",
     "asm_mg_coarse_failures",
     "asm_mg_graph_replays",
     "asm_mg_comm_init",
@@ -270,6 +272,8 @@ def load_library():
     lib.asm_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.asm_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     lib.asm_tiled_laplace_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.asm_pair_sweeps_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.asm_pair_plan.argtypes = [C.POINTER(AsmParams), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
     lib.asm_vec_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.asm_vec_multi_dot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_double)]
     lib.asm_vec_multi_axpy_norm.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.c_int32,
@@ -317,6 +321,19 @@ def tiled_plan(params, n_cu=256, rows=0):
     if err:
         raise ValueError(lib.asm_last_error(None).decode())
     keys = ("ntx", "nty", "nzc", "zlen", "x_first", "y_first", "owned_x", "owned_y")
+    return dict(zip(keys, list(plan))), list(order[: n.value])
+
+
+def pair_plan(params, n_cu=256):
+    """asm_pair_plan: (plan dict, order list) of the degree-4 wave-pair sweeps for the block `params` describes (host only)"""
+    lib = load_library()
+    plan, n = (C.c_int32 * 6)(), C.c_int32()
+    cap = 1 << 16
+    order = (C.c_int32 * cap)()
+    err = lib.asm_pair_plan(C.byref(params), n_cu, plan, order, cap, C.byref(n))
+    if err:
+        raise ValueError(lib.asm_last_error(None).decode())
+    keys = ("ntx", "nty", "nzc", "zlen", "x_first", "y_first")
     return dict(zip(keys, list(plan))), list(order[: n.value])
 
 
@@ -679,6 +696,12 @@ class Context:
         g = C.c_double()
         self._check(self.lib.asm_measure_copy_bandwidth(self.handle, bytes_per_array, reps, C.byref(g)))
         return g.value
+
+    def pair_sweeps(self):
+        """(laplace, fdm): which sweeps run on the wave-pair kernels"""
+        a, f = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.asm_pair_sweeps_in_use(self.handle, C.byref(a), C.byref(f)))
+        return bool(a.value), bool(f.value)
 
     def tiled_laplace_rows(self):
         r = C.c_int32()

@@ -79,6 +79,7 @@ struct asm_ctx
   // tiled kernels take the sweep); ASM_PAIR=0 switches them off
   DevKron                  kron_a{}, kron_p{};
   const int *              order_pair = nullptr; // work order of the wave-pair sweeps (pair_order)
+  bool                     pair_a = false, pair_p = false; // which sweeps take the wave-pair kernel (tune_pair)
   std::vector<void *>      allocs;
   bool                     ras_direct = true; // ASM_RAS_ATOMICS: restricted additive Schwarz through the atomics path on one rank too
   std::vector<double *>    work_pool; // released solver work vectors (asm_work_vector_*), kept until asm_destroy
@@ -578,7 +579,7 @@ namespace
   bool
   pair_laplace(asm_ctx *ctx, const TiledArgs &t, hipStream_t st)
   {
-    if (!pair_sweep(ctx->g, ctx->kron_a, t, st))
+    if (!ctx->pair_a || !pair_sweep(ctx->g, ctx->kron_a, t, st))
       return false;
     vec_constrained(ctx->g, t.mode == OP_PLAIN ? 0 : 2, t.dst, t.src, t.b, st); // 0, or r_c = b_c - x_c
     return true;
@@ -586,7 +587,7 @@ namespace
   bool
   pair_fdm(asm_ctx *ctx, const TiledArgs &t, hipStream_t st)
   {
-    if (!pair_sweep(ctx->g, ctx->kron_p, t, st))
+    if (!ctx->pair_p || !pair_sweep(ctx->g, ctx->kron_p, t, st))
       return false;
     FdmFused fu;
     fu.mode  = t.mode;
@@ -1083,6 +1084,96 @@ namespace
     HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     return ASM_OK;
   }
+
+  // Wave-pair or tiled kernel, per sweep: measured once per device, block shape and boundary kinds in a process (the
+  // faster one depends on how the tiles of either family fit the block); ASM_PAIR=1 / 0 takes the pair kernels wherever
+  // they apply / nowhere.  Called when everything else of the context stands (tables, work orders, scratch vectors).
+  std::map<std::array<int, 14>, int> g_pair_cache; // bit 0: A, bit 1: P
+  int
+  tune_pair(asm_ctx *ctx)
+  {
+    ctx->pair_a = ctx->pair_p = false;
+    if (!ctx->kron_a.valid && !ctx->kron_p.valid)
+      return ASM_OK;
+    if (const char *env = std::getenv("ASM_PAIR"))
+      {
+        ctx->pair_a = ctx->kron_a.valid && std::atoi(env) != 0;
+        ctx->pair_p = ctx->kron_p.valid && std::atoi(env) != 0;
+        return ASM_OK;
+      }
+    std::array<int, 14> key;
+    key[0] = ctx->device;
+    for (int d = 0; d < 3; ++d)
+      {
+        key[1 + d]  = ctx->g.nc[d];
+        key[4 + d]  = ctx->g.wrap[d];
+        key[7 + d]  = ctx->g.dir_lo[d] * 2 + ctx->g.dir_hi[d];
+        key[10 + d] = ctx->g.ext_hi[d] - ctx->g.ext_lo[d];
+      }
+    key[13] = (ctx->kron_a.valid ? 1 : 0) | (ctx->kron_p.valid ? 2 : 0) | (ctx->s.prm.weighting_type << 2);
+    {
+      std::lock_guard<std::mutex> lock(g_tune_mutex);
+      const auto                  hit = g_pair_cache.find(key);
+      if (hit != g_pair_cache.end())
+        {
+          ctx->pair_a = (hit->second & 1) != 0;
+          ctx->pair_p = (hit->second & 2) != 0;
+          return ASM_OK;
+        }
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    // the forms the Chebyshev iteration uses, on zero vectors: T = S - A R, T = R + f2 P^-1 S
+    const auto time_of = [&](const bool fdm, const bool pair) -> float {
+      TiledArgs a = fdm ? TiledArgs{PC_STEP1, ctx->S, ctx->T, nullptr, ctx->R, nullptr, 1., 0.5} :
+                          TiledArgs{OP_RESIDUAL, ctx->R, ctx->T, ctx->S, nullptr, nullptr, 0., 0.};
+      a.device     = ctx->device;
+      a.n_cu       = ctx->n_cu;
+      a.rows       = ctx->laplace_rows;
+      a.order      = fdm ? ctx->order_p : ctx->order_a;
+      a.pair_order = ctx->order_pair;
+      const auto launch = [&]() {
+        if (pair)
+          {
+            const bool was_a = ctx->pair_a, was_p = ctx->pair_p;
+            ctx->pair_a = ctx->pair_p = true;
+            const bool ok = fdm ? pair_fdm(ctx, a, ctx->stream) : pair_laplace(ctx, a, ctx->stream);
+            ctx->pair_a   = was_a;
+            ctx->pair_p   = was_p;
+            return ok;
+          }
+        return fdm ? fdm_tiled(ctx->g, ctx->f, a, ctx->stream) : laplace_tiled(ctx->g, ctx->op, a, ctx->stream);
+      };
+      bool ok = true;
+      for (int rep = 0; rep < 2 && ok; ++rep)
+        ok = launch();
+      (void)hipEventRecord(e0, ctx->stream);
+      for (int rep = 0; rep < 4 && ok; ++rep)
+        ok = launch();
+      (void)hipEventRecord(e1, ctx->stream);
+      float ms = 1e30f;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)
+        ok = false;
+      return ok ? ms : 1e30f;
+    };
+    int pick = 0;
+    if (ctx->kron_a.valid && ctx->s.laplace_tiled)
+      pick |= time_of(false, true) < 0.98f * time_of(false, false) ? 1 : 0;
+    if (ctx->kron_p.valid && ctx->s.fdm_tiled)
+      pick |= time_of(true, true) < 0.98f * time_of(true, false) ? 2 : 0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ctx->pair_a = (pick & 1) != 0;
+    ctx->pair_p = (pick & 2) != 0;
+    {
+      std::lock_guard<std::mutex> lock(g_tune_mutex);
+      g_pair_cache[key] = pick;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+    return ASM_OK;
+  }
+
 
   // eigenvalues of a symmetric tridiagonal matrix through the dense Jacobi solver
   double
@@ -1761,6 +1852,8 @@ asm_create(const asm_params *p, asm_ctx **out)
             return fail(err);
         }
     }
+  if ((err = tune_pair(ctx)))
+    return fail(err);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess)
     {
       ctx->error = "device error during setup";
@@ -2497,6 +2590,48 @@ asm_profile_get(asm_ctx *ctx, int kernel, int64_t *launches, double *total_ms)
     }
   *launches = (int64_t)ctx->prof_used[kernel];
   *total_ms = sum;
+  return ASM_OK;
+}
+
+// which sweeps of a tiled context take the wave-pair kernels (kernels_pair.hip; measured at creation against the tiled
+// kernels, or fixed by ASM_PAIR): *laplace / *fdm = 1 or 0
+int
+asm_pair_sweeps_in_use(const asm_ctx *ctx, int32_t *laplace, int32_t *fdm)
+{
+  if (!ctx || !laplace || !fdm)
+    return ASM_ERR_INVALID_VALUE;
+  *laplace = ctx->pair_a ? 1 : 0;
+  *fdm     = ctx->pair_p ? 1 : 0;
+  return ASM_OK;
+}
+
+// the tiling and work order of the wave-pair sweeps for the block `p` describes (host only, no device needed):
+// plan = {tiles x, tiles y, z chunks, layers per chunk, first cell of tile 0 in x, in y}
+int
+asm_pair_plan(const asm_params *p, int32_t n_cu, int32_t plan[6], int32_t *order, int32_t max_order, int32_t *n_order)
+{
+  if (p == nullptr || plan == nullptr || n_order == nullptr)
+    return ASM_ERR_INVALID_VALUE;
+  HostSetup s;
+  if (!setup_layout(*p, s))
+    {
+      g_create_error = s.error;
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (s.g.p != 4)
+    {
+      g_create_error = "asm_pair_plan: the wave-pair sweeps exist for degree 4";
+      return ASM_ERR_NOT_SUPPORTED;
+    }
+  int out[6];
+  pair_plan(s.g, n_cu, out);
+  for (int i = 0; i < 6; ++i)
+    plan[i] = out[i];
+  std::vector<int> ord;
+  *n_order = pair_order(s.g, n_cu, ord);
+  if (order != nullptr)
+    for (int i = 0; i < std::min<int>(max_order, (int)ord.size()); ++i)
+      order[i] = ord[i];
   return ASM_OK;
 }
 

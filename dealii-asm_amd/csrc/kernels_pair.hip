@@ -185,6 +185,37 @@ namespace asmamd
         line5<FWD>(v[0 * 5 + i], v[1 * 5 + i], v[2 * 5 + i], v[3 * 5 + i], v[4 * 5 + i], q);
     }
 
+    // Per-lane conditions live as bits of ONE vector register and are tested where they are used: as booleans the
+    // compiler would keep each of them as a 64-bit lane mask in two scalar registers over the whole march, and the kernel's
+    // scalar registers do not suffice for that (they went to vector lanes and back: ~200 moves per layer)
+    enum LaneFlag : unsigned
+    {
+      F_CELL   = 1u,    // the cell is computed
+      F_OWNER  = 2u,    // the lane stores DoFs (its cell, or the cell that does not exist but owns the last plane)
+      F_PH_X   = 4u,    // ... of which only column 0 exists
+      F_PH_Y   = 8u,    // ... of which only row 0 exists
+      F_XD0    = 16u,   // column 0 is a Dirichlet plane: not stored
+      F_YD0    = 32u,   // row 0 is a Dirichlet plane: not stored
+      F_LEFT   = 64u,   // the lane to the left belongs to the tile
+      F_BELOW  = 128u,  // the lane below belongs to the tile
+      F_NSX    = 256u,  // the cell's x class has no even-odd form
+      F_NSY    = 512u,  // the cell's y class has no even-odd form
+      F_SM_X0  = 1024u, // source DoFs read as zero (Laplace operator at Dirichlet faces): column 0, column 4, row 0, row 4
+      F_SM_X4  = 2048u,
+      F_SM_Y0  = 4096u,
+      F_SM_Y4  = 8192u
+    };
+    struct Lane
+    {
+      unsigned flags;
+      unsigned srow8[N1]; // source: byte offset of DoF row j of the cell inside a plane (cells not computed: cell 0)
+      unsigned sd4;       // ... and the step from column 0 to column 4 (periodic seam), bytes
+      unsigned orow8[P];  // operands / dst: byte offset of DoF row j of the DoFs the lane owns
+      __device__ __forceinline__ bool is(const unsigned f) const { return (flags & f) != 0u; }
+      // (the tests are made again in every layer instead of being kept as lane masks over the march)
+      __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(flags)); }
+    };
+
     // The x and y matrices of a lane (its cell's classes): the even-odd forms in LDS [.. 50: F 16][66: B 16], per lane;
     // lanes whose class has no even-odd form (nsx / nsy; any_*: some lane of the wave) are redone class by class with
     // the full matrix of the class as scalar operands.
@@ -192,7 +223,7 @@ namespace asmamd
     {
       lds_cptr      mx, my;
       int           clx, cly;
-      bool          nsx, nsy, any_nsx, any_nsy;
+      bool          any_nsx, any_nsy;
       bool          dup; // the unmasked copy of the even-odd sweep for waves without such lanes (not in the three-term kernel:
                          // it costs the compiler registers that kernel does not have to spare)
       const double *gx, *gy; // the tables of the x / y classes in global memory: [class][KRON_MAT_STRIDE]
@@ -200,9 +231,19 @@ namespace asmamd
     // one sweep direction of a plane
     template <bool FWD, bool XDIR>
     __device__ __forceinline__ void
-    sweep_dir(double (&v)[NE], const XYMatrices &m)
+    sweep_dir(double (&v)[NE], const XYMatrices &m, const Lane &c)
     {
-      const bool ns = XDIR ? m.nsx : m.nsy;
+#ifdef ASM_PAIR_ONLY_EO // diagnostic build: no full-matrix paths (results wrong at boundaries)
+      {
+        const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 50 : 66));
+        if (XDIR)
+          sweep_x<FWD>(v, q);
+        else
+          sweep_y<FWD>(v, q);
+        return;
+      }
+#endif
+      const bool ns = c.is(XDIR ? F_NSX : F_NSY);
       if (m.dup && !(XDIR ? m.any_nsx : m.any_nsy))
         {
           // (the common case, wave-uniform: no lane masks, no copies at a join)
@@ -246,17 +287,17 @@ namespace asmamd
     // x-y transform of one plane v[j * 5 + i]: forward x then y with F, backward y then x with B
     template <bool FWD>
     __device__ __forceinline__ void
-    plane2d(double (&v)[NE], const XYMatrices &m)
+    plane2d(double (&v)[NE], const XYMatrices &m, const Lane &c)
     {
       if (FWD)
         {
-          sweep_dir<true, true>(v, m);
-          sweep_dir<true, false>(v, m);
+          sweep_dir<true, true>(v, m, c);
+          sweep_dir<true, false>(v, m, c);
         }
       else
         {
-          sweep_dir<false, false>(v, m);
-          sweep_dir<false, true>(v, m);
+          sweep_dir<false, false>(v, m, c);
+          sweep_dir<false, true>(v, m, c);
         }
     }
 
@@ -292,7 +333,11 @@ namespace asmamd
     __device__ __forceinline__ void
     plane_request_row(const double *plane, const unsigned o, const unsigned o4)
     {
-      asm volatile("global_load_dwordx4 a[%3:%4], %0, %2\n\t"
+      // (s_nop: the base may just have come back from a vector lane - v_readlane writes the scalar register, and a vector
+      //  memory instruction that reads a scalar register a VALU instruction wrote needs 5 wait states in between; the
+      //  compiler pads for that hazard everywhere except in front of an asm statement, whose content it does not know)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 a[%3:%4], %0, %2\n\t"
                    "global_load_dwordx4 a[%5:%6], %0, %2 offset:16\n\t"
                    "global_load_dwordx2 a[%7:%8], %1, %2" ::"v"(o),
                    "v"(o4), "s"(plane), "n"(A0 + 10 * J), "n"(A0 + 10 * J + 3), "n"(A0 + 10 * J + 4), "n"(A0 + 10 * J + 7), "n"(A0 + 10 * J + 8),
@@ -303,7 +348,8 @@ namespace asmamd
     __device__ __forceinline__ void
     operand_request_row(const double *plane, const unsigned o)
     {
-      asm volatile("global_load_dwordx4 a[%2:%3], %0, %1\n\t"
+      asm volatile("s_nop 4\n\t" // (as above)
+                   "global_load_dwordx4 a[%2:%3], %0, %1\n\t"
                    "global_load_dwordx4 a[%4:%5], %0, %1 offset:16" ::"v"(o),
                    "s"(plane), "n"(A0 + 8 * J), "n"(A0 + 8 * J + 3), "n"(A0 + 8 * J + 4), "n"(A0 + 8 * J + 7)
                    : "memory");
@@ -340,19 +386,6 @@ namespace asmamd
       aregs_to<A0 + 40>(&v[20], std::make_integer_sequence<int, 5>());
     }
     // ---------------------------------------------------------------------------------------------------------------
-    struct Lane
-    {
-      bool cell_xy;           // the cell is computed
-      bool owner;             // the lane stores DoFs (its cell, or the cell that does not exist but owns the last plane)
-      bool ph_x, ph_y;        // ... of which only column 0 / row 0 exist
-      bool xd0, yd0;          // column 0 / row 0 is a Dirichlet plane: not stored
-      bool left_ok, below_ok; // the lane to the left / below belongs to the tile
-      unsigned smask;         // source DoFs read as zero: bit 0 / 1: column 0 / 4, bit 2 / 3: row 0 / 4 (Laplace operator at Dirichlet faces)
-      unsigned srow8[N1];     // source: byte offset of DoF row j of the cell inside a plane (cells not computed: cell 0)
-      unsigned sd4;           // ... and the step from column 0 to column 4 (periodic seam), bytes
-      unsigned orow8[P];      // operands / dst: byte offset of DoF row j of the DoFs the lane owns
-    };
-
     template <int A0>
     __device__ __forceinline__ void
     plane_request(const double *plane, const Lane &c)
@@ -383,14 +416,37 @@ namespace asmamd
           for (int e = 0; e < NE; ++e)
             v[e] = 0.;
         }
-      else if (c.smask != 0u)
+      else if (c.is(F_SM_X0 | F_SM_X4 | F_SM_Y0 | F_SM_Y4))
         {
 #pragma unroll
           for (int j = 0; j < N1; ++j)
 #pragma unroll
             for (int i = 0; i < N1; ++i)
-              if ((i == 0 && (c.smask & 1u)) || (i == 4 && (c.smask & 2u)) || (j == 0 && (c.smask & 4u)) || (j == 4 && (c.smask & 8u)))
+              if ((i == 0 && c.is(F_SM_X0)) || (i == 4 && c.is(F_SM_X4)) || (j == 0 && c.is(F_SM_Y0)) || (j == 4 && c.is(F_SM_Y4)))
                 v[j * 5 + i] = 0.;
+        }
+    }
+
+    // one tenth of the requests of the next layer's two planes (step 0..9 = plane step / 5, row step % 5): spread over
+    // the z columns instead of issued in one burst, which the vector memory path accepts at 60 cycles per request
+    // (stage timers, profiles/r04_pair_stamps.txt)
+    template <int AS0, int AS1>
+    __device__ __forceinline__ void
+    plane_request_step(const int step, const double *p0, const double *p1, const Lane &c)
+    {
+      switch (step)
+        {
+          case 0: plane_request_row<AS0, 0>(p0, c.srow8[0], c.srow8[0] + c.sd4); break;
+          case 1: plane_request_row<AS0, 1>(p0, c.srow8[1], c.srow8[1] + c.sd4); break;
+          case 2: plane_request_row<AS0, 2>(p0, c.srow8[2], c.srow8[2] + c.sd4); break;
+          case 3: plane_request_row<AS0, 3>(p0, c.srow8[3], c.srow8[3] + c.sd4); break;
+          case 4: plane_request_row<AS0, 4>(p0, c.srow8[4], c.srow8[4] + c.sd4); break;
+          case 5: plane_request_row<AS1, 0>(p1, c.srow8[0], c.srow8[0] + c.sd4); break;
+          case 6: plane_request_row<AS1, 1>(p1, c.srow8[1], c.srow8[1] + c.sd4); break;
+          case 7: plane_request_row<AS1, 2>(p1, c.srow8[2], c.srow8[2] + c.sd4); break;
+          case 8: plane_request_row<AS1, 3>(p1, c.srow8[3], c.srow8[3] + c.sd4); break;
+          case 9: plane_request_row<AS1, 4>(p1, c.srow8[4], c.srow8[4] + c.sd4); break;
+          default: break;
         }
     }
 
@@ -431,7 +487,7 @@ namespace asmamd
     emit_row(const TiledArgs &a, const Lane &c, double *__restrict__ dplane, const double (&o)[NE])
     {
       using MT = ModeTraits<MODE>;
-      if (J == 0 ? !c.yd0 : !c.ph_y)
+      if (J == 0 ? !c.is(F_YD0) : !c.is(F_PH_Y))
         {
           double xa[P] = {0., 0., 0., 0.}, xb[P] = {0., 0., 0., 0.};
           if (MT::need_a)
@@ -444,12 +500,12 @@ namespace asmamd
           lo.y = fused_update<MODE>(a, o[J * 5 + 1], xa[1], xb[1]);
           hi.x = fused_update<MODE>(a, o[J * 5 + 2], xa[2], xb[2]);
           hi.y = fused_update<MODE>(a, o[J * 5 + 3], xa[3], xb[3]);
-          if (c.ph_x)
+          if (c.is(F_PH_X))
             {
-              if (!c.xd0)
+              if (!c.is(F_XD0))
                 __builtin_nontemporal_store(lo.x, d);
             }
-          else if (c.xd0)
+          else if (c.is(F_XD0))
             {
               __builtin_nontemporal_store(lo.y, d + 1);
               __builtin_nontemporal_store(hi, (dbl2_u *)(d + 2));
@@ -473,7 +529,7 @@ namespace asmamd
       for (int j = 0; j < N1; ++j)
         {
           const double r = lane_left(o[j * 5 + 4]);
-          if (c.left_ok)
+          if (c.is(F_LEFT))
             o[j * 5 + 0] += r;
         }
       // y: row 4 of the cell below -> row 0
@@ -481,13 +537,13 @@ namespace asmamd
 #pragma unroll
       for (int i = 0; i < P; ++i)
         rb[i] = __shfl_up(o[4 * 5 + i], TX, 64);
-      if (c.below_ok)
+      if (c.is(F_BELOW))
         {
 #pragma unroll
           for (int i = 0; i < P; ++i)
             o[0 * 5 + i] += rb[i];
         }
-      if (c.owner && !plane_constrained)
+      if (c.is(F_OWNER) && !plane_constrained)
         {
           emit_row<MODE, 0, AXA, AXB>(a, c, dplane, o);
           emit_row<MODE, 1, AXA, AXB>(a, c, dplane, o);
@@ -505,7 +561,7 @@ namespace asmamd
 
 #ifdef ASM_PAIR_STAMP
     // diagnostic build: cycles (s_memtime) one interior wave spends per stage, summed over its layers
-    __device__ unsigned long long g_pair_stamps[16];
+    __device__ unsigned long long g_pair_stamps[24];
 #  define PSTAMP(i)                                                    \
     do                                                                 \
       {                                                                \
@@ -536,7 +592,7 @@ namespace asmamd
       const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
 #ifdef ASM_PAIR_STAMP
       const bool         stamp_on = tx == tl.ntx / 2 && ty == tl.nty / 2 && zc == tl.nzc / 2 && threadIdx.x < 64;
-      unsigned long long stamp_t = __builtin_amdgcn_s_memtime(), stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long stamp_t = __builtin_amdgcn_s_memtime(), stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
       const int lane = threadIdx.x & 63, cl = lane % TX, rw = lane / TX;
@@ -544,37 +600,36 @@ namespace asmamd
       const int cx = X0 + cl, cy = Y0 + rw;
       Lane      c;
       int       clx = 0, cly = 0;
+      bool      cell_xy, owner, ph_x, ph_y;
       {
         const bool comp_x = cell_computable(g, 0, cx), comp_y = cell_computable(g, 1, cy);
-        c.ph_x            = cx == g.nc[0] && has_phantom(g, 0);
-        c.ph_y            = cy == g.nc[1] && has_phantom(g, 1);
-        c.cell_xy         = comp_x && comp_y;
+        ph_x              = cx == g.nc[0] && has_phantom(g, 0);
+        ph_y              = cy == g.nc[1] && has_phantom(g, 1);
+        cell_xy           = comp_x && comp_y;
         // a cell's DoFs (0..3)^2 belong to the tile that holds it outside its halo column / row; cells -1 are never owned
-        const bool own_x = cx >= 0 && (comp_x || c.ph_x) && (cl >= 1 || (tx == 0 && tl.x_first == 0));
-        const bool own_y = cy >= 0 && (comp_y || c.ph_y) && (rw >= 1 || (ty == 0 && tl.y_first == 0));
-        c.owner          = own_x && own_y;
-        c.left_ok        = cl >= 1;
-        c.below_ok       = rw >= 1;
-        c.xd0            = c.owner && g.dirichlet(0, P * cx);
-        c.yd0            = c.owner && g.dirichlet(1, P * cy);
-        c.smask          = 0u;
-        if (kr.mask_constrained && c.cell_xy)
-          c.smask = (g.dirichlet(0, P * cx) ? 1u : 0u) | (g.dirichlet(0, P * cx + P) ? 2u : 0u) | (g.dirichlet(1, P * cy) ? 4u : 0u) |
-                    (g.dirichlet(1, P * cy + P) ? 8u : 0u);
+        const bool own_x = cx >= 0 && (comp_x || ph_x) && (cl >= 1 || (tx == 0 && tl.x_first == 0));
+        const bool own_y = cy >= 0 && (comp_y || ph_y) && (rw >= 1 || (ty == 0 && tl.y_first == 0));
+        owner            = own_x && own_y;
+        c.flags          = (cell_xy ? F_CELL : 0u) | (owner ? F_OWNER : 0u) | (ph_x ? F_PH_X : 0u) | (ph_y ? F_PH_Y : 0u) |
+                  ((owner && g.dirichlet(0, P * cx)) ? F_XD0 : 0u) | ((owner && g.dirichlet(1, P * cy)) ? F_YD0 : 0u) | (cl >= 1 ? F_LEFT : 0u) |
+                  (rw >= 1 ? F_BELOW : 0u);
+        if (kr.mask_constrained && cell_xy)
+          c.flags |= (g.dirichlet(0, P * cx) ? F_SM_X0 : 0u) | (g.dirichlet(0, P * cx + P) ? F_SM_X4 : 0u) | (g.dirichlet(1, P * cy) ? F_SM_Y0 : 0u) |
+                     (g.dirichlet(1, P * cy + P) ? F_SM_Y4 : 0u);
         // source rows: the cell itself, or cell (0, 0) for lanes without a computed cell (any finite data: zero diagonal)
-        const int sx = c.cell_xy ? cx : 0, sy = c.cell_xy ? cy : 0;
+        const int sx = cell_xy ? cx : 0, sy = cell_xy ? cy : 0;
         const int x0 = g.store_index_near(0, P * sx);
         c.sd4        = (unsigned)(g.store_index_near(0, P * sx + P) - x0) * 8u;
 #pragma unroll
         for (int j = 0; j < N1; ++j)
           c.srow8[j] = (unsigned)(g.store_index_near(1, P * sy + j) * (int)g.stride[1] + x0) * 8u;
         // owned rows: rows 1..3 of a cell that only owns row 0 do not exist
-        const int ox = c.owner ? cx : 0, oy = c.owner ? cy : 0;
+        const int ox = owner ? cx : 0, oy = owner ? cy : 0;
         const int xo = g.store_index_near(0, P * ox);
 #pragma unroll
         for (int j = 0; j < P; ++j)
-          c.orow8[j] = (unsigned)(g.store_index_near(1, P * oy + ((c.owner && c.ph_y) ? 0 : j)) * (int)g.stride[1] + xo) * 8u;
-        if (c.cell_xy)
+          c.orow8[j] = (unsigned)(g.store_index_near(1, P * oy + ((owner && ph_y) ? 0 : j)) * (int)g.stride[1] + xo) * 8u;
+        if (cell_xy)
           {
             clx = kr.cls[0][cx + 1];
             cly = kr.cls[1][cy + 1];
@@ -594,16 +649,18 @@ namespace asmamd
       mxy.my      = Ml + (1 * KRON_MAX_CLS + cly) * KRON_MAT_STRIDE;
       mxy.clx     = clx;
       mxy.cly     = cly;
-      mxy.nsx     = c.cell_xy && kr.sym[0 * KRON_MAX_CLS + clx] == 0;
-      mxy.nsy     = c.cell_xy && kr.sym[1 * KRON_MAX_CLS + cly] == 0;
-      mxy.any_nsx = __any(mxy.nsx);
-      mxy.any_nsy = __any(mxy.nsy);
+      {
+        const bool nsx = cell_xy && kr.sym[0 * KRON_MAX_CLS + clx] == 0, nsy = cell_xy && kr.sym[1 * KRON_MAX_CLS + cly] == 0;
+        c.flags |= (nsx ? F_NSX : 0u) | (nsy ? F_NSY : 0u);
+        mxy.any_nsx = __any(nsx);
+        mxy.any_nsy = __any(nsy);
+      }
       mxy.dup     = !MT::need_b;
       mxy.gx      = kr.mat + 0 * KRON_MAX_CLS * KRON_MAT_STRIDE;
       mxy.gy      = kr.mat + 1 * KRON_MAX_CLS * KRON_MAT_STRIDE;
       // this lane's diagonal: column e of this wave at Dz + 5 e (cells that are not computed: zeros)
       const int      col0 = NZC * role;
-      const lds_cptr Dz   = c.cell_xy ? Dl + (cly * KRON_MAX_CLS + clx) * KRON_DIAG_STRIDE + col0 * N1 : Zl;
+      const lds_cptr Dz   = cell_xy ? Dl + (cly * KRON_MAX_CLS + clx) * KRON_DIAG_STRIDE + col0 * N1 : Zl;
 
       // scratchpad addresses of this lane: forward planes of this wave, its z columns, its backward planes
       const lds_ptr X_fwd = Xl + (2 * role) * NE * 64;
@@ -624,6 +681,12 @@ namespace asmamd
       areg_reserve();
       __syncthreads(); // tables in LDS
       int clz_cached = -1;
+      // the z classes: this layer's was loaded a layer ago; which of them have an even-odd form
+      int      clz_next = uniform_load(kr.cls[2], z_first + 1);
+      unsigned sym_z    = 0u;
+#pragma unroll
+      for (int q = 0; q < KRON_MAX_CLS; ++q)
+        sym_z |= (uniform_load(kr.sym, 2 * KRON_MAX_CLS + q) != 0 ? 1u : 0u) << q;
       // ---- prologue: plane 0 of the first layer (wave 0 transforms it, both pick their columns), first requests
       {
         const long long z0 = plane_offset(g, P * z_first);
@@ -646,7 +709,7 @@ namespace asmamd
             operand_request<AR::XB0>(a.x_old + plane_offset(g, P * z_first + kb), c);
             operand_request<AR::XB1>(a.x_old + plane_offset(g, P * z_first + kb + 1), c);
           }
-        plane2d<true>(v, mxy);
+        plane2d<true>(v, mxy, c);
         if (role == 0)
           {
 #pragma unroll
@@ -663,9 +726,11 @@ namespace asmamd
       for (int cz = z_first; cz < Ze; ++cz)
         {
           const bool emit = cz >= Zb, more = cz + 1 < Ze;
+          c.refresh();
           PSTAMP(0);
           // the diagonals of this layer's z class
-          const int clz = uniform_load(kr.cls[2], cz + 1);
+          const int clz = clz_next;
+          clz_next      = uniform_load(kr.cls[2], min(cz + 2, g.nc[2] + 1));
           if (clz != clz_cached)
             {
               // (the scratchpad barriers below order these writes against the reads of the layer before)
@@ -674,18 +739,20 @@ namespace asmamd
                 Dl[e] = src[e];
               clz_cached = clz;
             }
+          PSTAMP(6);
           // ---- forward x-y transforms of this wave's two planes -> scratchpad
           {
             if (cz == z_first || cz == Zb || MT::n_operand_requests == 0)
               vm_wait<0>(); // first layers of a chunk, or nothing but the stores of the layer below is younger
             else
               vm_wait<MT::n_operand_requests>(); // younger than the plane requests: the operand requests of this layer
+            PSTAMP(7);
             {
               double v[NE];
               plane_unpack<AR::S0>(v);
               if (kr.mask_constrained)
                 mask_source(v, c, false); // (planes 1..3 of a layer are never Dirichlet planes)
-              plane2d<true>(v, mxy);
+              plane2d<true>(v, mxy, c);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 X_fwd[(0 * NE + e) * 64] = v[e];
@@ -695,20 +762,18 @@ namespace asmamd
               plane_unpack<AR::S1>(v);
               if (kr.mask_constrained)
                 mask_source(v, c, g.dirichlet(2, P * cz + kf + 1));
-              plane2d<true>(v, mxy);
+              plane2d<true>(v, mxy, c);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 X_fwd[(1 * NE + e) * 64] = v[e];
             }
-            // the next layer's planes: a whole layer ahead
-            if (more)
-              {
-                plane_request<AR::S0>(a.src + plane_offset(g, P * (cz + 1) + kf), c);
-                plane_request<AR::S1>(a.src + plane_offset(g, P * (cz + 1) + kf + 1), c);
-              }
+            PSTAMP(8);
           }
+          // the next layer's planes are requested a whole layer ahead, one row per z column below
+          const double *const next0 = a.src + plane_offset(g, P * (cz + (more ? 1 : 0)) + kf);
+          const double *const next1 = a.src + plane_offset(g, P * (cz + (more ? 1 : 0)) + kf + 1);
           const lds_cptr      mz    = Ml + (2 * KRON_MAX_CLS + clz) * KRON_MAT_STRIDE;
-          const bool          eo_z  = uniform_load(kr.sym, 2 * KRON_MAX_CLS + clz) != 0;
+          const bool          eo_z  = ((sym_z >> clz) & 1u) != 0u;
           PSTAMP(1);
           __syncthreads();
           PSTAMP(2);
@@ -724,6 +789,8 @@ namespace asmamd
               for (int e = 0; e < NZC; ++e)
                 if (e < NZC - 1 || role == 0)
                   {
+                    if (more)
+                      plane_request_step<AR::S0, AR::S1>(e, next0, next1, c);
                     double       u0 = t0[e], u1 = n1, u2 = n2, u3 = n3, u4 = n4;
                     const double d0 = nd[0], d1 = nd[1], d2 = nd[2], d3 = nd[3], d4 = nd[4];
                     if (e + 1 < NZC && (e + 1 < NZC - 1 || role == 0))
@@ -754,7 +821,11 @@ namespace asmamd
                     carry[e] = u4;
                   }
             };
+#if defined(ASM_PAIR_ONLY_EO) && ASM_PAIR_ONLY_EO == 2
+            if (true)
+#else
             if (eo_z)
+#endif
               columns(EoCoef(mz + 50), EoCoef(mz + 66));
             else
               {
@@ -775,33 +846,56 @@ namespace asmamd
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 w[e] = X_bwd[(0 * NE + e) * 64];
+              PSTAMP(9);
               if (cz == Zb || !more)
                 vm_wait<0>();
               else
                 vm_wait<30>(); // younger than the operand requests: the 30 plane requests of this layer
-              plane2d<false>(w, mxy);
+              PSTAMP(10);
+              plane2d<false>(w, mxy, c);
               emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo0, w, con0);
+              // (the next layer's operands of this plane: its registers are free)
+              if (more)
+                {
+                  if (MT::need_a)
+                    operand_request<AR::XA0>(opA + plane_offset(g, P * (cz + 1) + kb), c);
+                  if (MT::need_b)
+                    operand_request<AR::XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
+                }
+              PSTAMP(11);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 w[e] = X_bwd[(1 * NE + e) * 64];
+              PSTAMP(12);
               __syncthreads(); // the scratchpad may take the next layer's planes
-              plane2d<false>(w, mxy);
+              PSTAMP(13);
+              plane2d<false>(w, mxy, c);
               emit_plane<MODE, AR::XA1, AR::XB1>(a, c, a.dst + zo1, w, false);
+              if (more)
+                {
+                  if (MT::need_a)
+                    operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                  if (MT::need_b)
+                    operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                }
+              PSTAMP(14);
             }
           else
-            __syncthreads();
-          if (more)
             {
-              // the next layer's update operands
-              if (MT::need_a)
+              __syncthreads();
+              if (more)
                 {
-                  operand_request<AR::XA0>(opA + plane_offset(g, P * (cz + 1) + kb), c);
-                  operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
-                }
-              if (MT::need_b)
-                {
-                  operand_request<AR::XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
-                  operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                  // halo layer: the update operands of the first owned layer
+                  if (MT::need_a)
+                    {
+                      operand_request<AR::XA0>(opA + plane_offset(g, P * (cz + 1) + kb), c);
+                      operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                    }
+                  if (MT::need_b)
+                    {
+                      operand_request<AR::XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
+                      operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                    }
                 }
             }
         }
@@ -809,9 +903,9 @@ namespace asmamd
       PSTAMP(5);
       if (stamp_on && lane == 0)
         {
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < 16; ++i)
             atomicAdd(&g_pair_stamps[i], stamp_acc[i]);
-          atomicAdd(&g_pair_stamps[8], (unsigned long long)(Ze - z_first));
+          atomicAdd(&g_pair_stamps[16], (unsigned long long)(Ze - z_first));
         }
 #endif
       if (Ze == g.nc[2] && has_phantom(g, 2))
@@ -835,7 +929,7 @@ namespace asmamd
               if (MT::need_b)
                 operand_request<AR::XB0>(a.x_old + zo, c);
               vm_wait<0>();
-              plane2d<false>(v, mxy);
+              plane2d<false>(v, mxy, c);
               emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo, v, false);
             }
         }
@@ -999,13 +1093,13 @@ namespace asmamd
 #ifdef ASM_PAIR_STAMP
   // stage cycles of the diagnostic build (tools/pair_stamps.py); not part of the C ABI
   extern "C" void
-  asm_debug_pair_stamps(unsigned long long out[16], int reset)
+  asm_debug_pair_stamps(unsigned long long out[24], int reset)
   {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stamps), 16 * sizeof(unsigned long long));
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stamps), 24 * sizeof(unsigned long long));
     if (reset)
       {
-        unsigned long long z[16] = {};
+        unsigned long long z[24] = {};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), z, sizeof(z));
       }
   }

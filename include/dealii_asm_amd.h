@@ -350,6 +350,14 @@ int asm_measure_copy_bandwidth(asm_ctx *ctx, int64_t bytes, int32_t reps, double
  * order[i] = work index taken by launch position i of a single-phase launch (*n_order entries, 0: launch order = work
  * order).  Diagnostic: lets the tiling be checked without a device (tests/test_abi_cpu.py). */
 int asm_tiled_plan(const asm_params *p, int32_t n_cu, int32_t rows, int32_t plan[8], int32_t *order, int32_t max_order, int32_t *n_order);
+/* The same for the wave-pair sweeps (degree 4 on Cartesian cells; csrc/kernels_pair.hip): plan = {tiles x, tiles y, z chunks,
+ * layers per chunk, first cell of tile 0 in x, in y}; a tile = 8 x 8 cells of which 7 x 7 (all 8 where tile 0 starts at
+ * cell 0) own their DoFs, the cell behind the block's last one owns the block's last DoF plane. */
+int asm_pair_plan(const asm_params *p, int32_t n_cu, int32_t plan[6], int32_t *order, int32_t max_order, int32_t *n_order);
+/* which sweeps of a tiled context run on the wave-pair kernels (measured against the tiled kernels when the context is
+ * created; ASM_PAIR=1 / 0 fixes it): *laplace, *fdm = 1 / 0.  Replaces the same reference methods as the tiled kernels:
+ * LaplaceOperatorMatrixFree::vmult (include/operator.h:1367-1430), ASPoissonPreconditioner::vmult (include/matrix_free.h:1023-1062). */
+int asm_pair_sweeps_in_use(const asm_ctx *ctx, int32_t *laplace, int32_t *fdm);
 /* Cell rows (waves) per workgroup of the context's tiled Laplace sweep: 8 = first generation, 9 / 10 / 11 = second
  * (picked by a measurement at creation, or ASM_TILED_ROWS); 0 = no tiled Laplace sweep.  Reported by bench.py. */
 int asm_tiled_laplace_rows(const asm_ctx *ctx, int32_t *rows);

@@ -1,0 +1,7 @@
+#!/bin/bash
+# bench.py with another build of the library: bench_lib.sh <path to .so> [bench args]
+export DEALII_ASM_AMD_LIB="$1"; shift
+python "$(dirname "$0")/../bench.py" "$@" 2>/dev/null | python -c "
+import json,sys
+d = json.loads(sys.stdin.read().strip().split('\n')[-1])
+print(d['ms_per_step'], {k: round(v['avg_ms'], 4) for k, v in d['roofline']['kernels'].items()}, d['north_star_point']['ms_per_step'], {k: round(v['avg_ms'], 4) for k, v in d['north_star_point']['kernels'].items()})"

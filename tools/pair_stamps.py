@@ -19,7 +19,7 @@ b = ctx.vector(np.ones(ctx.n_owned))
 x = ctx.vector()
 lib = ctx.lib
 lib.asm_debug_pair_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 for _ in range(3):
     ctx.cheb_step(x, b)
 lib.asm_debug_pair_stamps(out, 1)
@@ -27,11 +27,13 @@ n = 10
 for _ in range(n):
     ctx.cheb_step(x, b)
 lib.asm_debug_pair_stamps(out, 1)
-names = ["emit tail + operand requests -> top of layer", "diagonal refresh, wait, forward x-y of two planes, plane requests", "barrier 1",
-         "z columns", "barrier 2", "(after the loop)"]
-layers = out[8]
+names = {0: "operand requests of the next layer -> top of layer", 6: "z class, diagonal refresh", 7: "wait for the planes", 8: "unpack, forward x-y of two planes, LDS writes",
+         1: "plane requests of the next layer", 2: "barrier 1", 3: "z columns", 4: "barrier 2", 9: "LDS reads of output plane 0", 10: "wait for the operands",
+         11: "backward x-y, merge, update, store of plane 0", 12: "LDS reads of output plane 1", 13: "barrier 3", 14: "backward x-y, merge, update, store of plane 1"}
+layers = out[16]
 print("cells", nc, "- A and P sweeps together, %d wave-layers" % layers)
-tot = sum(out[i] for i in range(5))
-for i in range(5):
+order = [6, 7, 8, 1, 2, 3, 4, 9, 10, 11, 12, 13, 14, 0]
+tot = sum(out[i] for i in order)
+for i in order:
     print("  %-70s %8.0f cycles/layer  %5.1f %%" % (names[i], out[i] / layers, 100.0 * out[i] / tot))
-print("  %-70s %8.0f cycles/layer" % ("total (stage 0 holds backward x-y, merge, update, stores, barrier 3)", tot / layers))
+print("  %-70s %8.0f cycles/layer" % ("total", tot / layers))

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../dealii-asm_amd"
 mkdir -p abl/build_pairstamp
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -I/opt/rocm/include -DASM_PAIR_STAMP"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -I/opt/rocm/include -DASM_PAIR_STAMP $PAIR_EXTRA"
 for f in context kernels_generic kernels_vector kernels_tiled multigrid kernels_slice7 kernels_small kernels_pair; do
   /opt/rocm/bin/hipcc $F -c csrc/$f.hip -o abl/build_pairstamp/$f.o &
 done

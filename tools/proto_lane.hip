@@ -313,8 +313,13 @@ emit_plane(const Args &a, const Lane &c, const int K, double (&o)[NE], const dou
               __builtin_nontemporal_store(lo.x, d + j * a.sy);
             else
               {
+#if ABL & 32
+                *(dbl2_u *)(d + j * a.sy)     = lo;
+                *(dbl2_u *)(d + j * a.sy + 2) = hi;
+#else
                 __builtin_nontemporal_store(lo, (dbl2_u *)(d + j * a.sy));
                 __builtin_nontemporal_store(hi, (dbl2_u *)(d + j * a.sy + 2));
+#endif
               }
           }
     }
