@@ -212,3 +212,28 @@ def test_chunk_count_model_of_the_tiled_sweeps(pkg):
     assert plan["nzc"] == 8 and plan["zlen"] == 10
     plan, _ = pkg.tiled_plan(pkg.make_params(degree=4, n_cells=(128, 64, 64), boundary="periodic"))
     assert plan["nzc"] == 2
+
+
+@pytest.mark.parametrize("nc,boundary", [((80, 80, 80), "dirichlet"), ((128, 128, 96), "dirichlet"), ((7, 8, 3), "dirichlet"), ((15, 9, 4), "neumann"),
+                                         ((16, 16, 9), "periodic"), ((1, 1, 1), "dirichlet"), ((23, 57, 5), "dirichlet")])
+def test_pair_plan_covers_the_block(pkg, nc, boundary):
+    """asm_pair_plan (host only): the tiles of the wave-pair sweeps (8 x 8 cells, 7 x 7 of them owned, all 8 where tile 0
+    starts at cell 0) own every cell of the block once, plus the cell behind the last one where the block owns its last DoF
+    plane; the z chunks cover the layers; the work order is a permutation that keeps every XCD's contiguous range"""
+    prm = pkg.make_params(degree=4, n_cells=nc, boundary=boundary)
+    plan, order = pkg.pair_plan(prm, n_cu=256)
+    periodic = boundary == "periodic"
+    for d, (nt, first) in enumerate(((plan["ntx"], plan["x_first"]), (plan["nty"], plan["y_first"]))):
+        assert first == (-1 if periodic else 0)
+        last = nc[d] - 1 if periodic else nc[d]  # non-periodic: the cell nc owns the plane 4 nc
+        owned = []
+        for t in range(nt):
+            c0 = t * 7 + first
+            owned += [c for c in range(c0, c0 + 8) if 0 <= c <= last and (c > c0 or (t == 0 and first == 0))]
+        assert sorted(owned) == list(range(last + 1)), (d, owned)
+    assert plan["nzc"] * plan["zlen"] >= nc[2] and (plan["nzc"] - 1) * plan["zlen"] < nc[2]
+    n = plan["ntx"] * plan["nty"] * plan["nzc"]
+    assert len(order) == n and sorted(order) == list(range(n))
+    for xcd in range(8):
+        begin, count = xcd * (n // 8) + min(xcd, n % 8), n // 8 + (1 if xcd < n % 8 else 0)
+        assert sorted(order[begin:begin + count]) == list(range(begin, begin + count))
