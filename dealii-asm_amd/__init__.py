@@ -715,7 +715,7 @@ class Context:
 class Multigrid:
     """Level hierarchy + V-cycle (PreconditionerGMG, include/multigrid.h:40-520) over contexts of this library."""
 
-    def __init__(self, fine_params: AsmParams, mg_type="h", p_sequence="bisect", one_sided=False, coarse="cg",
+    def __init__(self, fine_params: AsmParams, mg_type="h", p_sequence="bisect", one_sided=False, coarse="auto",
                  coarse_rel_tol=1e-3, coarse_max_iter=200, estimate_eigenvalues=True, n_coarse_cycles=1,
                  intermediate_smoother=None, keep_duplicate_level=True):
         """intermediate_smoother: None ("mg intermediate smoother" without a type = the mg smoother) or

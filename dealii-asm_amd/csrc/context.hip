@@ -1042,7 +1042,11 @@ namespace
             std::vector<int> order;
             tiled_order(ctx->g, ctx->n_cu, cand[i], order);
             if (const int err = upload(ctx, order, &order_of[i]))
-              return err;
+              {
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                return err;
+              }
           }
         // the residual form the Chebyshev iteration uses: dst = T, src = R, b = S (zero vectors)
         TiledArgs a{OP_RESIDUAL, ctx->R, ctx->T, ctx->S, nullptr, nullptr, 0., 0.};
@@ -1124,7 +1128,13 @@ namespace
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    // the forms the Chebyshev iteration uses, on zero vectors: T = S - A R, T = R + f2 P^-1 S
+    // operands that are not all zero (the clock the chip holds, and with it which family is faster, depends on the data)
+    {
+      const long long gb[3] = {0, 0, 0}, gs[3] = {1 << 20, 1 << 20, 1 << 20};
+      vec_initial_guess(ctx->g, ctx->R, gb, gs, ctx->stream);
+      vec_initial_guess(ctx->g, ctx->S, gb, gs, ctx->stream);
+    }
+    // the forms the Chebyshev iteration uses: T = S - A R, T = R + f2 P^-1 S
     const auto time_of = [&](const bool fdm, const bool pair) -> float {
       TiledArgs a = fdm ? TiledArgs{PC_STEP1, ctx->S, ctx->T, nullptr, ctx->R, nullptr, 1., 0.5} :
                           TiledArgs{OP_RESIDUAL, ctx->R, ctx->T, ctx->S, nullptr, nullptr, 0., 0.};
@@ -1149,7 +1159,7 @@ namespace
       for (int rep = 0; rep < 2 && ok; ++rep)
         ok = launch();
       (void)hipEventRecord(e0, ctx->stream);
-      for (int rep = 0; rep < 4 && ok; ++rep)
+      for (int rep = 0; rep < 6 && ok; ++rep)
         ok = launch();
       (void)hipEventRecord(e1, ctx->stream);
       float ms = 1e30f;
@@ -1157,11 +1167,21 @@ namespace
         ok = false;
       return ok ? ms : 1e30f;
     };
+    // (two interleaved rounds per family, the better of each: a box's clock drifts within the measurement)
+    const auto faster = [&](const bool fdm) {
+      float tp = 1e30f, tt = 1e30f;
+      for (int round = 0; round < 2; ++round)
+        {
+          tp = std::min(tp, time_of(fdm, true));
+          tt = std::min(tt, time_of(fdm, false));
+        }
+      return tp < 0.98f * tt;
+    };
     int pick = 0;
     if (ctx->kron_a.valid && ctx->s.laplace_tiled)
-      pick |= time_of(false, true) < 0.98f * time_of(false, false) ? 1 : 0;
+      pick |= faster(false) ? 1 : 0;
     if (ctx->kron_p.valid && ctx->s.fdm_tiled)
-      pick |= time_of(true, true) < 0.98f * time_of(true, false) ? 2 : 0;
+      pick |= faster(true) ? 2 : 0;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ctx->pair_a = (pick & 1) != 0;
@@ -1171,6 +1191,8 @@ namespace
       g_pair_cache[key] = pick;
     }
     HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->R, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->S, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     return ASM_OK;
   }
 
@@ -1691,7 +1713,8 @@ asm_create(const asm_params *p, asm_ctx **out)
       // z chunk of the box alone
       f.s7_flag[0] = f.s7_flag[1] = f.s7_flag[2] = nullptr;
       f.s7_lz                                    = 0;
-      if (f.s7_on && f.origin_mul == 4 && s.prm.world_size == 1 && s.prm.weighting_type != ASM_W_RAS && std::getenv("ASM_S7_TMP") == nullptr)
+      if (f.s7_on && f.origin_mul == 4 && s.prm.world_size == 1 && !s.self_interface && s.prm.weighting_type != ASM_W_RAS &&
+          std::getenv("ASM_S7_TMP") == nullptr) // (the predicate of multi_rank(): the accumulate form runs on one rank only)
         {
           const int n2 = f.s7_hi[2] - f.s7_lo[2];
           const int columns = ((f.s7_hi[0] - f.s7_lo[0] + S7_TILE_X - 1) / S7_TILE_X) * ((f.s7_hi[1] - f.s7_lo[1] + S7_TILE_Y - 1) / S7_TILE_Y);

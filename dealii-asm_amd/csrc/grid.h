@@ -128,7 +128,7 @@ namespace asmamd
   // B = F_ref, D = hy hz / hx la + hx hz / hy lb + hx hy / hz lc) differ in these tables only.  A cell's class per
   // direction selects its matrices; the class triple selects the diagonal.  Device pointers.
   constexpr int KRON_MAX_CLS    = 4;   // classes per direction
-  constexpr int KRON_MAT_STRIDE = 88;  // doubles per (direction, class): F[i][a] 25, B[i][a] 25, F even-odd 16, B even-odd 16
+  constexpr int KRON_MAT_STRIDE = 96;  // doubles per (direction, class): F^T [a][6] 30 (column a of F, padded), B [i][6] 30, F even-odd 16, B even-odd 16
   constexpr int KRON_DIAG_STRIDE = 128; // doubles per class triple: D[(b * 5 + a) * 5 + c]
   struct DevKron
   {

@@ -107,13 +107,25 @@ namespace asmamd
       __device__ __forceinline__ double E(const int a, const int i) const { return e[a * 3 + i]; }
       __device__ __forceinline__ double O(const int a, const int i) const { return o[a * 2 + i]; }
     };
-    // full matrix [i][a] of ONE class (cells at a boundary have no even-odd form): wave-uniform, read from the table in
-    // global memory by scalar loads, so that its 25 numbers are scalar operands of the FMAs and cost no vector registers
-    // (the even-odd path leaves none to spare: the compiler must never spill into the accumulation registers, see below)
+    // full matrix (cells at a boundary have no even-odd form): five rows of six in LDS, output r = row r . input, for the
+    // forward sweep the rows of F^T, for the backward sweep the rows of B.  The pointer is the lane's own (its cell's class)
+    // or wave-uniform (z): no lane masks, no scalar loads.  The rows are read again for every line - 25 coefficients held
+    // over a sweep would push the compiler into the accumulation registers this kernel keeps for itself.
     struct FullCoef
     {
+      lds_cptr q;
+      __device__ __forceinline__ explicit FullCoef(lds_cptr m)
+        : q(m)
+      {}
+    };
+
+    // The same rows as scalar operands (scalar loads from the table in global memory), for ONE class at a time: no vector
+    // registers at all.  The three-term update's kernel takes this form under lane masks, class by class: its second
+    // operand leaves the compiler 28 accumulation registers, the LDS form above makes it spill 92 values.
+    struct FullCoefS
+    {
       const __attribute__((address_space(4))) double *q;
-      __device__ __forceinline__ explicit FullCoef(const double *m)
+      __device__ __forceinline__ explicit FullCoefS(const double *m)
         : q((const __attribute__((address_space(4))) double *)m)
       {}
     };
@@ -150,18 +162,33 @@ namespace asmamd
     __device__ __forceinline__ void
     line5(double &u0, double &u1, double &u2, double &u3, double &u4, const FullCoef &c)
     {
+      // (a pointer the compiler cannot trace and that exists only once this line's input does: the reads of this line are
+      //  neither merged with those of the line before nor issued lines ahead, which would cost 30 registers per line)
+      lds_cptr q = c.q;
+      asm volatile("" : "+v"(q) : "v"(u0));
+      double o[N1];
+#pragma unroll
+      for (int r = 0; r < N1; ++r)
+        {
+          const dbl2   q01 = *(const __attribute__((address_space(3))) dbl2 *)(q + r * 6), q23 = *(const __attribute__((address_space(3))) dbl2 *)(q + r * 6 + 2);
+          const double q4  = q[r * 6 + 4];
+          o[r]             = fma(q4, u4, fma(q23.y, u3, fma(q23.x, u2, fma(q01.y, u1, q01.x * u0))));
+        }
+      u0 = o[0];
+      u1 = o[1];
+      u2 = o[2];
+      u3 = o[3];
+      u4 = o[4];
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void
+    line5(double &u0, double &u1, double &u2, double &u3, double &u4, const FullCoefS &c)
+    {
       const __attribute__((address_space(4))) double *q = c.q;
       double                                          o[N1];
 #pragma unroll
-      for (int a = 0; a < N1; ++a)
-        {
-          double s = (FWD ? q[0 * N1 + a] : q[a * N1 + 0]) * u0;
-          s        = fma(FWD ? q[1 * N1 + a] : q[a * N1 + 1], u1, s);
-          s        = fma(FWD ? q[2 * N1 + a] : q[a * N1 + 2], u2, s);
-          s        = fma(FWD ? q[3 * N1 + a] : q[a * N1 + 3], u3, s);
-          s        = fma(FWD ? q[4 * N1 + a] : q[a * N1 + 4], u4, s);
-          o[a]     = s;
-        }
+      for (int r = 0; r < N1; ++r)
+        o[r] = fma(q[r * 6 + 4], u4, fma(q[r * 6 + 3], u3, fma(q[r * 6 + 2], u2, fma(q[r * 6 + 1], u1, q[r * 6 + 0] * u0))));
       u0 = o[0];
       u1 = o[1];
       u2 = o[2];
@@ -216,38 +243,34 @@ namespace asmamd
       __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(flags)); }
     };
 
-    // The x and y matrices of a lane (its cell's classes): the even-odd forms in LDS [.. 50: F 16][66: B 16], per lane;
-    // lanes whose class has no even-odd form (nsx / nsy; any_*: some lane of the wave) are redone class by class with
-    // the full matrix of the class as scalar operands.
+    // The x and y matrices of a lane (its cell's classes) in LDS: [F^T 30][B 30][F even-odd 16][B even-odd 16].
+    // any_ns* (wave-uniform): some cell of the wave has a class without an even-odd form in that direction.  LDSFULL: the
+    // whole wave then takes the full matrices there (25 instead of 17 operations per line, every lane with its own
+    // class's rows from LDS); otherwise (three-term kernel) the lanes of such classes are redone class by class under
+    // lane masks with scalar operands.
     struct XYMatrices
     {
       lds_cptr      mx, my;
-      int           clx, cly;
       bool          any_nsx, any_nsy;
-      bool          dup; // the unmasked copy of the even-odd sweep for waves without such lanes (not in the three-term kernel:
-                         // it costs the compiler registers that kernel does not have to spare)
+      int           clx, cly;
       const double *gx, *gy; // the tables of the x / y classes in global memory: [class][KRON_MAT_STRIDE]
     };
     // one sweep direction of a plane
-    template <bool FWD, bool XDIR>
+    template <bool FWD, bool XDIR, bool LDSFULL>
     __device__ __forceinline__ void
     sweep_dir(double (&v)[NE], const XYMatrices &m, const Lane &c)
     {
-#ifdef ASM_PAIR_ONLY_EO // diagnostic build: no full-matrix paths (results wrong at boundaries)
-      {
-        const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 50 : 66));
-        if (XDIR)
-          sweep_x<FWD>(v, q);
-        else
-          sweep_y<FWD>(v, q);
-        return;
-      }
-#endif
-      const bool ns = c.is(XDIR ? F_NSX : F_NSY);
-      if (m.dup && !(XDIR ? m.any_nsx : m.any_nsy))
+      if (LDSFULL && !(XDIR ? m.any_nsx : m.any_nsy))
         {
-          // (the common case, wave-uniform: no lane masks, no copies at a join)
-          const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 50 : 66));
+          const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 60 : 76));
+          if (XDIR)
+            sweep_x<FWD>(v, q);
+          else
+            sweep_y<FWD>(v, q);
+        }
+      else if (LDSFULL)
+        {
+          const FullCoef q((XDIR ? m.mx : m.my) + (FWD ? 0 : 30));
           if (XDIR)
             sweep_x<FWD>(v, q);
           else
@@ -255,9 +278,10 @@ namespace asmamd
         }
       else
         {
+          const bool ns = c.is(XDIR ? F_NSX : F_NSY);
           if (!ns)
             {
-              const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 50 : 66));
+              const EoCoef q((XDIR ? m.mx : m.my) + (FWD ? 60 : 76));
               if (XDIR)
                 sweep_x<FWD>(v, q);
               else
@@ -265,7 +289,7 @@ namespace asmamd
             }
           if (!(XDIR ? m.any_nsx : m.any_nsy))
             return;
-          // (wave-uniform loop over the classes without an even-odd form that occur in the wave: none, or one)
+          // (wave-uniform loop over the classes without an even-odd form that occur in the wave: one, rarely two)
           const int          cls  = XDIR ? m.clx : m.cly;
           unsigned long long todo = __ballot(ns);
           while (todo != 0ull)
@@ -274,7 +298,7 @@ namespace asmamd
               const bool mine = ns && cls == c0;
               if (mine)
                 {
-                  const FullCoef q((XDIR ? m.gx : m.gy) + (long long)c0 * KRON_MAT_STRIDE + (FWD ? 0 : 25));
+                  const FullCoefS q((XDIR ? m.gx : m.gy) + (long long)c0 * KRON_MAT_STRIDE + (FWD ? 0 : 30));
                   if (XDIR)
                     sweep_x<FWD>(v, q);
                   else
@@ -285,19 +309,19 @@ namespace asmamd
         }
     }
     // x-y transform of one plane v[j * 5 + i]: forward x then y with F, backward y then x with B
-    template <bool FWD>
+    template <bool FWD, bool LDSFULL>
     __device__ __forceinline__ void
     plane2d(double (&v)[NE], const XYMatrices &m, const Lane &c)
     {
       if (FWD)
         {
-          sweep_dir<true, true>(v, m, c);
-          sweep_dir<true, false>(v, m, c);
+          sweep_dir<true, true, LDSFULL>(v, m, c);
+          sweep_dir<true, false, LDSFULL>(v, m, c);
         }
       else
         {
-          sweep_dir<false, false>(v, m, c);
-          sweep_dir<false, true>(v, m, c);
+          sweep_dir<false, false, LDSFULL>(v, m, c);
+          sweep_dir<false, true, LDSFULL>(v, m, c);
         }
     }
 
@@ -561,7 +585,7 @@ namespace asmamd
 
 #ifdef ASM_PAIR_STAMP
     // diagnostic build: cycles (s_memtime) one interior wave spends per stage, summed over its layers
-    __device__ unsigned long long g_pair_stamps[24];
+    __device__ unsigned long long g_pair_stamps[6][24]; // [mode]
 #  define PSTAMP(i)                                                    \
     do                                                                 \
       {                                                                \
@@ -584,6 +608,7 @@ namespace asmamd
       extern __shared__ __attribute__((aligned(16))) double lds[];
       using MT = ModeTraits<MODE>;
       using AR = ARegs<MT::need_b>;
+      constexpr bool LDSFULL = !MT::need_b; // (see XYMatrices)
       // workgroups b and b + 8 land on the same XCD: contiguous ranges of the work per XCD (L2 locality of neighbouring tiles)
       int wi = (int)xcd_block(blockIdx.x, gridDim.x);
       if (a.pair_order != nullptr) // expensive workgroups first (pair_order); a scalar load
@@ -645,19 +670,18 @@ namespace asmamd
       for (int e = threadIdx.x; e < L_ZERO; e += 128)
         Zl[e] = 0.;
       XYMatrices mxy;
-      mxy.mx      = Ml + (0 * KRON_MAX_CLS + clx) * KRON_MAT_STRIDE;
-      mxy.my      = Ml + (1 * KRON_MAX_CLS + cly) * KRON_MAT_STRIDE;
-      mxy.clx     = clx;
-      mxy.cly     = cly;
+      mxy.mx = Ml + (0 * KRON_MAX_CLS + clx) * KRON_MAT_STRIDE;
+      mxy.my = Ml + (1 * KRON_MAX_CLS + cly) * KRON_MAT_STRIDE;
       {
         const bool nsx = cell_xy && kr.sym[0 * KRON_MAX_CLS + clx] == 0, nsy = cell_xy && kr.sym[1 * KRON_MAX_CLS + cly] == 0;
         c.flags |= (nsx ? F_NSX : 0u) | (nsy ? F_NSY : 0u);
         mxy.any_nsx = __any(nsx);
         mxy.any_nsy = __any(nsy);
+        mxy.clx     = clx;
+        mxy.cly     = cly;
+        mxy.gx      = kr.mat + 0 * KRON_MAX_CLS * KRON_MAT_STRIDE;
+        mxy.gy      = kr.mat + 1 * KRON_MAX_CLS * KRON_MAT_STRIDE;
       }
-      mxy.dup     = !MT::need_b;
-      mxy.gx      = kr.mat + 0 * KRON_MAX_CLS * KRON_MAT_STRIDE;
-      mxy.gy      = kr.mat + 1 * KRON_MAX_CLS * KRON_MAT_STRIDE;
       // this lane's diagonal: column e of this wave at Dz + 5 e (cells that are not computed: zeros)
       const int      col0 = NZC * role;
       const lds_cptr Dz   = cell_xy ? Dl + (cly * KRON_MAX_CLS + clx) * KRON_DIAG_STRIDE + col0 * N1 : Zl;
@@ -709,7 +733,7 @@ namespace asmamd
             operand_request<AR::XB0>(a.x_old + plane_offset(g, P * z_first + kb), c);
             operand_request<AR::XB1>(a.x_old + plane_offset(g, P * z_first + kb + 1), c);
           }
-        plane2d<true>(v, mxy, c);
+        plane2d<true, LDSFULL>(v, mxy, c);
         if (role == 0)
           {
 #pragma unroll
@@ -752,7 +776,7 @@ namespace asmamd
               plane_unpack<AR::S0>(v);
               if (kr.mask_constrained)
                 mask_source(v, c, false); // (planes 1..3 of a layer are never Dirichlet planes)
-              plane2d<true>(v, mxy, c);
+              plane2d<true, LDSFULL>(v, mxy, c);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 X_fwd[(0 * NE + e) * 64] = v[e];
@@ -762,7 +786,7 @@ namespace asmamd
               plane_unpack<AR::S1>(v);
               if (kr.mask_constrained)
                 mask_source(v, c, g.dirichlet(2, P * cz + kf + 1));
-              plane2d<true>(v, mxy, c);
+              plane2d<true, LDSFULL>(v, mxy, c);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 X_fwd[(1 * NE + e) * 64] = v[e];
@@ -821,17 +845,14 @@ namespace asmamd
                     carry[e] = u4;
                   }
             };
-#if defined(ASM_PAIR_ONLY_EO) && ASM_PAIR_ONLY_EO == 2
-            if (true)
-#else
             if (eo_z)
-#endif
-              columns(EoCoef(mz + 50), EoCoef(mz + 66));
+              columns(EoCoef(mz + 60), EoCoef(mz + 76));
+            else if (LDSFULL)
+              columns(FullCoef(mz), FullCoef(mz + 30)); // first / last layer of a block with Dirichlet or Neumann faces
             else
               {
-                // first / last layer of a block with Dirichlet or Neumann faces: full matrices, scalar operands
                 const double *gz = kr.mat + (long long)(2 * KRON_MAX_CLS + clz) * KRON_MAT_STRIDE;
-                columns(FullCoef(gz), FullCoef(gz + 25));
+                columns(FullCoefS(gz), FullCoefS(gz + 30));
               }
           }
           PSTAMP(3);
@@ -852,7 +873,7 @@ namespace asmamd
               else
                 vm_wait<30>(); // younger than the operand requests: the 30 plane requests of this layer
               PSTAMP(10);
-              plane2d<false>(w, mxy, c);
+              plane2d<false, LDSFULL>(w, mxy, c);
               emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo0, w, con0);
               // (the next layer's operands of this plane: its registers are free)
               if (more)
@@ -869,7 +890,7 @@ namespace asmamd
               PSTAMP(12);
               __syncthreads(); // the scratchpad may take the next layer's planes
               PSTAMP(13);
-              plane2d<false>(w, mxy, c);
+              plane2d<false, LDSFULL>(w, mxy, c);
               emit_plane<MODE, AR::XA1, AR::XB1>(a, c, a.dst + zo1, w, false);
               if (more)
                 {
@@ -904,8 +925,8 @@ namespace asmamd
       if (stamp_on && lane == 0)
         {
           for (int i = 0; i < 16; ++i)
-            atomicAdd(&g_pair_stamps[i], stamp_acc[i]);
-          atomicAdd(&g_pair_stamps[16], (unsigned long long)(Ze - z_first));
+            atomicAdd(&g_pair_stamps[MODE][i], stamp_acc[i]);
+          atomicAdd(&g_pair_stamps[MODE][16], (unsigned long long)(Ze - z_first));
         }
 #endif
       if (Ze == g.nc[2] && has_phantom(g, 2))
@@ -929,7 +950,7 @@ namespace asmamd
               if (MT::need_b)
                 operand_request<AR::XB0>(a.x_old + zo, c);
               vm_wait<0>();
-              plane2d<false>(v, mxy, c);
+              plane2d<false, LDSFULL>(v, mxy, c);
               emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo, v, false);
             }
         }
@@ -1093,13 +1114,13 @@ namespace asmamd
 #ifdef ASM_PAIR_STAMP
   // stage cycles of the diagnostic build (tools/pair_stamps.py); not part of the C ABI
   extern "C" void
-  asm_debug_pair_stamps(unsigned long long out[24], int reset)
+  asm_debug_pair_stamps(unsigned long long out[6 * 24], int reset)
   {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stamps), 24 * sizeof(unsigned long long));
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stamps), 6 * 24 * sizeof(unsigned long long));
     if (reset)
       {
-        unsigned long long z[24] = {};
+        unsigned long long z[6 * 24] = {};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), z, sizeof(z));
       }
   }

@@ -427,6 +427,24 @@ namespace asmamd
     const long long n = (long long)(g.own_hi[0] + 1) * (g.own_hi[1] + 1) * (g.own_hi[2] + 1);
     hipLaunchKernelGGL(add_scalar_owned_kernel, dim3(grid_for(n, 4)), dim3(VB), 0, st, g, v, a);
   }
+  namespace
+  {
+    // blocks per face of the kernels over the Dirichlet planes: one thread per DoF of the largest face (64 blocks per
+    // face, as these kernels were launched until round 4, left every thread six dependent round trips on the 80^3 block:
+    // 20 us behind every sweep of the wave-pair kernels, which leave the constrained DoFs to them)
+    unsigned
+    face_blocks(const DevGrid &g, const int threads)
+    {
+      long long n = 1;
+      for (int d = 0; d < 3; ++d)
+        {
+          const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+          const long long n1 = g.wrap[d1] ? g.nc[d1] * g.p : g.ext_hi[d1] - g.ext_lo[d1] + 1, n2 = g.wrap[d2] ? g.nc[d2] * g.p : g.ext_hi[d2] - g.ext_lo[d2] + 1;
+          n = std::max(n, n1 * n2);
+        }
+      return (unsigned)std::max<long long>(1, std::min<long long>((n + threads - 1) / threads, 2048));
+    }
+  } // namespace
   void
   vec_constrained(const DevGrid &g, int mode, double *dst, const double *src, const double *b, hipStream_t st)
   {
@@ -435,7 +453,7 @@ namespace asmamd
       any = any || g.dir_lo[d] || g.dir_hi[d];
     if (!any)
       return;
-    hipLaunchKernelGGL(constrained_kernel, dim3(64, 6), dim3(VB), 0, st, g, mode, dst, src, b);
+    hipLaunchKernelGGL(constrained_kernel, dim3(face_blocks(g, VB), 6), dim3(VB), 0, st, g, mode, dst, src, b);
   }
   namespace
   {
@@ -472,7 +490,7 @@ namespace asmamd
       any = any || g.dir_lo[d] || g.dir_hi[d];
     if (!any)
       return;
-    hipLaunchKernelGGL(constrained_fused_kernel, dim3(64, 6), dim3(VB), 0, st, g, fu, dst, src);
+    hipLaunchKernelGGL(constrained_fused_kernel, dim3(face_blocks(g, VB), 6), dim3(VB), 0, st, g, fu, dst, src);
   }
   namespace
   {

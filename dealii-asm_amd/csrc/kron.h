@@ -32,23 +32,26 @@ namespace asmamd
     store_matrices(HostKron &k, const int d, const int c, const double F[25], const double B[25], const bool sym)
     {
       double *m = &k.mat[(size_t)(d * KRON_MAX_CLS + c) * KRON_MAT_STRIDE];
-      for (int e = 0; e < 25; ++e)
-        {
-          m[e]      = F[e];
-          m[25 + e] = B[e];
-        }
-      // E[a][i] = q[i][a] (a, i < 3), O[a][i] = q[i][3 + a] (a, i < 2)
+      // full forms, one output per row of six (16-byte aligned rows): forward out[a] = sum_i F[i][a] in[i] reads row a of
+      // F^T, backward out[i] = sum_a B[i][a] in[a] reads row i of B
+      for (int r = 0; r < 5; ++r)
+        for (int q = 0; q < 5; ++q)
+          {
+            m[r * 6 + q]      = F[q * 5 + r];
+            m[30 + r * 6 + q] = B[r * 5 + q];
+          }
+      // even-odd forms: E[a][i] = q[i][a] (a, i < 3), O[a][i] = q[i][3 + a] (a, i < 2)
       for (int a = 0; a < 3; ++a)
         for (int i = 0; i < 3; ++i)
           {
-            m[50 + a * 3 + i] = F[i * 5 + a];
-            m[66 + a * 3 + i] = B[i * 5 + a];
+            m[60 + a * 3 + i] = F[i * 5 + a];
+            m[76 + a * 3 + i] = B[i * 5 + a];
           }
       for (int a = 0; a < 2; ++a)
         for (int i = 0; i < 2; ++i)
           {
-            m[50 + 9 + a * 2 + i] = F[i * 5 + 3 + a];
-            m[66 + 9 + a * 2 + i] = B[i * 5 + 3 + a];
+            m[60 + 9 + a * 2 + i] = F[i * 5 + 3 + a];
+            m[76 + 9 + a * 2 + i] = B[i * 5 + 3 + a];
           }
       k.sym[d * KRON_MAX_CLS + c] = sym ? 1 : 0;
     }

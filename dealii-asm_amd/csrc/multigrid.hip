@@ -1256,6 +1256,14 @@ int
 asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
 {
   *out = nullptr;
+  // (the size is checked through the pointer BEFORE the structure is copied: a full-size copy of a shorter structure
+  //  would read past the caller's object.  struct_size is the structure's last member, so the check recognises a
+  //  structure that asm_mg_params_default did not fill; it cannot recognise a caller built against a shorter revision.)
+  if (mp_in && mp_in->struct_size != (uint32_t)sizeof(asm_mg_params))
+    {
+      g_mg_create_error = "asm_mg_params: struct_size does not match this library (initialise with asm_mg_params_default)";
+      return ASM_ERR_INVALID_VALUE;
+    }
   asm_mg_params mp;
   if (mp_in)
     mp = *mp_in;

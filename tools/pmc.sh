@@ -5,6 +5,7 @@
 # of every sweep kernel variant that ran (ASM_TILED_ROWS=0 keeps the context from launching the other
 # Laplace variants while it tunes).  PMC_BENCH_ARGS="--n-overlap 2 --degree 2" selects another workload.
 R=$PWD
+rm -rf $R/gpurun_out/pmc_[0-9]*   # (every call reports its own passes only)
 export ASM_BENCH_LAMBDA=1.7
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -19,7 +20,7 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob('gpurun_out/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if not any(t in k for t in ('laplace_cart_tiled', 'fdm_tiled', 'laplace_generic', 'fdm_generic', 'fdm_gather', 'fdm_slice7', 's7_init')):
+        if not any(t in k for t in ('laplace_cart_tiled', 'fdm_tiled', 'laplace_generic', 'fdm_generic', 'fdm_gather', 'fdm_slice7', 's7_init', 'pair_sweep')):
             continue
         # kernel name with its template arguments, without the parameter list (the context's tuning launches of
         # other kernel variants stay separate rows)

@@ -17,5 +17,14 @@ rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/benc
 cd $R
 PMC_BENCH_ARGS="--no-north-star" tools/pmc.sh "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_traffic.txt
 PMC_BENCH_ARGS="--no-north-star --cells 128 128 96" tools/pmc.sh "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_traffic_north_star.txt
+# round 4: the wave-pair kernels forced (a context otherwise takes the faster family per sweep), and their stage timers
+ASM_PAIR=1 PMC_BENCH_ARGS="--no-north-star" tools/pmc.sh "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_traffic_pair.txt
+ASM_PAIR=1 PMC_BENCH_ARGS="--no-north-star --cells 128 128 96" tools/pmc.sh "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_traffic_pair_north_star.txt
+for p in 0 1; do for w in "" "--workload cart_periodic" "--degree 3" "--cells 128 128 96"; do
+  echo "ASM_PAIR=$p $w" >> $O/pair_vs_tiled.txt
+  ASM_PAIR=$p tools/bench_lib.sh dealii-asm_amd/libdealii_asm_amd.so --no-cpu-baseline --no-north-star $w >> $O/pair_vs_tiled.txt
+done; done
+if [ -f dealii-asm_amd/abl/lib_pairstamp.so ]; then ASM_PAIR=1 python tools/pair_stamps.py > $O/pair_stamps.txt 2>&1 || true; ASM_PAIR=1 python tools/pair_stamps.py 128 128 96 >> $O/pair_stamps.txt 2>&1 || true; fi
+(cd tools && hipcc -O3 --offload-arch=gfx950 -o microbench_issue microbench_issue.hip 2>/dev/null; ./microbench_issue > $O/microbench_issue.txt; hipcc -O3 --offload-arch=gfx950 -o proto_lane proto_lane.hip 2>/dev/null; for a in "80 80 80 7" "80 80 80 10" "128 128 96 4"; do ./proto_lane $a | grep "cells\|check\|stamps\|lane sweep" >> $O/proto_lane.txt; done)
 find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/kt gpurun_out/pmc_1 gpurun_out/pmc_2
