@@ -574,29 +574,18 @@ namespace
     return ASM_OK;
   }
 
-  // The wave-pair sweep where it applies (single-phase launches), with the constrained DoFs - which it neither reads nor
-  // writes - set from the untouched operands afterwards; false: not applicable, nothing launched
+  // The wave-pair sweep where it applies (single-phase launches); false: not applicable, nothing launched
   bool
   pair_laplace(asm_ctx *ctx, const TiledArgs &t, hipStream_t st)
   {
-    if (!ctx->pair_a || !pair_sweep(ctx->g, ctx->kron_a, t, st))
-      return false;
-    vec_constrained(ctx->g, t.mode == OP_PLAIN ? 0 : 2, t.dst, t.src, t.b, st); // 0, or r_c = b_c - x_c
-    return true;
+    // (the constrained DoFs - 0, or r_c = b_c - x_c - are set by the last workgroups of the same launch)
+    return ctx->pair_a && pair_sweep(ctx->g, ctx->kron_a, t, st);
   }
   bool
   pair_fdm(asm_ctx *ctx, const TiledArgs &t, hipStream_t st)
   {
-    if (!ctx->pair_p || !pair_sweep(ctx->g, ctx->kron_p, t, st))
-      return false;
-    FdmFused fu;
-    fu.mode  = t.mode;
-    fu.x     = t.x;
-    fu.x_old = t.x_old;
-    fu.f1    = t.f1;
-    fu.f2    = t.f2;
-    vec_constrained_fused(ctx->g, fu, t.dst, t.src, st); // unit rows of P^-1
-    return true;
+    // (the constrained DoFs - unit rows of P^-1 - are set by the last workgroups of the same launch)
+    return ctx->pair_p && pair_sweep(ctx->g, ctx->kron_p, t, st);
   }
 
   // launch a tiled sweep; inside cheb_run with several ranks: boundary workgroups, exchange of the

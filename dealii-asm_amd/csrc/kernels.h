@@ -96,7 +96,7 @@ namespace asmamd
   // ---- wave-pair sweep (kernels_pair.hip), degree 4, cell patches / box cells on tensor-product meshes: two waves share a
   //      tile of 8 x 8 cells (one lane per cell), march along z and apply the Kronecker-diagonal cell operator of the
   //      tables k with the fused update of a.mode; single-phase launches only (false: not applicable, nothing launched).
-  //      Constrained DoFs are neither read nor written: the caller sets them (vec_constrained / vec_constrained_fused).
+  //      The march neither reads nor writes constrained DoFs; further workgroups of the same launch set them (identity rows).
   bool pair_sweep(const DevGrid &g, const DevKron &k, const TiledArgs &a, hipStream_t st);
   // work order of the pair sweep (host side, device-independent): order[p] = work index (tile x fastest, tile y, z chunk)
   // of launch position p: every XCD keeps its contiguous range of the work but starts with its expensive workgroups (tiles

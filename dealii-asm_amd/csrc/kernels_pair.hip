@@ -65,6 +65,12 @@ namespace asmamd
     {
       int ntx, nty, nzc, zlen;
       int x_first, y_first; // first cell of tile 0: -1 where the block has a cell below its first one, else 0
+      // The Dirichlet planes, which the march neither reads nor writes, are set by n_face further workgroups at the end of
+      // the launch (identity rows: the fused update of the source value).  They start as compute units fall free in the
+      // launch's tail and cost next to nothing there; as a kernel of their own behind every sweep (vec_constrained*,
+      // 64-byte sectors for 8-byte values on the x faces) they took 24 us = 8 % of a sweep at 80^3.
+      int       n_face;
+      long long face_dofs; // DoFs of all Dirichlet planes (stored extent of the two tangential directions)
     };
 
     __device__ __forceinline__ bool
@@ -117,6 +123,25 @@ namespace asmamd
       __device__ __forceinline__ explicit FullCoef(lds_cptr m)
         : q(m)
       {}
+    };
+    // ... and the same 25 numbers held in registers over one sweep of a plane (five lines): the rows' LDS latency is paid
+    // once per sweep instead of once per line (410 cycles per line in a tile at a face, stage timers of round 4)
+    struct FullRegs
+    {
+      double r[N1][N1];
+      __device__ __forceinline__ explicit FullRegs(lds_cptr m)
+      {
+#pragma unroll
+        for (int k = 0; k < N1; ++k)
+          {
+            const dbl2 q01 = *(const __attribute__((address_space(3))) dbl2 *)(m + k * 6), q23 = *(const __attribute__((address_space(3))) dbl2 *)(m + k * 6 + 2);
+            r[k][0]        = q01.x;
+            r[k][1]        = q01.y;
+            r[k][2]        = q23.x;
+            r[k][3]        = q23.y;
+            r[k][4]        = m[k * 6 + 4];
+          }
+      }
     };
 
     // The same rows as scalar operands (scalar loads from the table in global memory), for ONE class at a time: no vector
@@ -174,6 +199,20 @@ namespace asmamd
           const double q4  = q[r * 6 + 4];
           o[r]             = fma(q4, u4, fma(q23.y, u3, fma(q23.x, u2, fma(q01.y, u1, q01.x * u0))));
         }
+      u0 = o[0];
+      u1 = o[1];
+      u2 = o[2];
+      u3 = o[3];
+      u4 = o[4];
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void
+    line5(double &u0, double &u1, double &u2, double &u3, double &u4, const FullRegs &c)
+    {
+      double o[N1];
+#pragma unroll
+      for (int r = 0; r < N1; ++r)
+        o[r] = fma(c.r[r][4], u4, fma(c.r[r][3], u3, fma(c.r[r][2], u2, fma(c.r[r][1], u1, c.r[r][0] * u0))));
       u0 = o[0];
       u1 = o[1];
       u2 = o[2];
@@ -270,7 +309,7 @@ namespace asmamd
         }
       else if (LDSFULL)
         {
-          const FullCoef q((XDIR ? m.mx : m.my) + (FWD ? 0 : 30));
+          const FullRegs q((XDIR ? m.mx : m.my) + (FWD ? 0 : 30));
           if (XDIR)
             sweep_x<FWD>(v, q);
           else
@@ -601,6 +640,61 @@ namespace asmamd
 #  define PSTAMP(i)
 #endif
 
+    // the constrained (Dirichlet) DoFs: dst = fused update of the identity row, i.e. with the cell operator's result
+    // replaced by the source value (0 for the plain products); A x = x there (matrix_free_internal.h:247-255), P^-1 has
+    // unit rows.  A DoF on an edge or corner lies on two or three planes: the plane of the lowest direction takes it (the
+    // three-term update is not idempotent when dst is x_old).  One work item per DoF, grid-stride over the face workgroups.
+    template <int MODE>
+    __device__ __forceinline__ void
+    constrained_dofs(const DevGrid &g, const TiledArgs &a, const long long first, const long long stride, const long long total)
+    {
+      const double *const opA = (MODE == OP_RESIDUAL) ? a.b : a.x;
+      for (long long item = first; item < total; item += stride)
+        {
+          long long e = item;
+          int       d = 0, side = 0;
+          long long n1 = 1;
+          bool      found = false;
+#pragma unroll
+          for (int f = 0; f < 6; ++f)
+            if (!found)
+              {
+                const int fd = f / 2, fs = f % 2;
+                if (fs ? g.dir_hi[fd] : g.dir_lo[fd])
+                  {
+                    const int       d1 = (fd + 1) % 3, d2 = (fd + 2) % 3;
+                    const long long m1 = g.wrap[d1] ? g.nc[d1] * g.p : g.ext_hi[d1] - g.ext_lo[d1] + 1,
+                                    m2 = g.wrap[d2] ? g.nc[d2] * g.p : g.ext_hi[d2] - g.ext_lo[d2] + 1;
+                    if (e < m1 * m2)
+                      {
+                        d     = fd;
+                        side  = fs;
+                        n1    = m1;
+                        found = true;
+                      }
+                    else
+                      e -= m1 * m2;
+                  }
+              }
+          if (!found)
+            continue;
+          const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+          int       c[3];
+          c[d]  = side ? g.nc[d] * g.p : 0;
+          c[d1] = (g.wrap[d1] ? 0 : g.ext_lo[d1]) + (int)(e % n1);
+          c[d2] = (g.wrap[d2] ? 0 : g.ext_lo[d2]) + (int)(e / n1);
+          bool earlier = false;
+          for (int dd = 0; dd < d; ++dd)
+            earlier = earlier || g.dirichlet(dd, c[dd]);
+          if (earlier)
+            continue;
+          const long long o = g.offset(c[0], c[1], c[2]);
+          const double    t = (MODE == OP_PLAIN || MODE == PC_PLAIN) ? 0. : a.src[o];
+          const double    oa = ModeTraits<MODE>::need_a ? opA[o] : 0., ob = ModeTraits<MODE>::need_b ? a.x_old[o] : 0.;
+          a.dst[o]           = fused_update<MODE>(a, t, oa, ob);
+        }
+    }
+
     // ---------------------------------------------------------------------------------------------------------------
     template <int MODE>
     __global__ void __launch_bounds__(128) pair_sweep_kernel(const DevGrid g, const DevKron kr, const TiledArgs a, const PairTiling tl)
@@ -610,13 +704,24 @@ namespace asmamd
       using AR = ARegs<MT::need_b>;
       constexpr bool LDSFULL = !MT::need_b; // (see XYMatrices)
       // workgroups b and b + 8 land on the same XCD: contiguous ranges of the work per XCD (L2 locality of neighbouring tiles)
-      int wi = (int)xcd_block(blockIdx.x, gridDim.x);
+      const int n_march = tl.ntx * tl.nty * tl.nzc;
+      if ((int)blockIdx.x >= n_march)
+        {
+          // (the last workgroups of the launch: the Dirichlet planes)
+          constrained_dofs<MODE>(g, a, ((long long)blockIdx.x - n_march) * 128 + threadIdx.x, (long long)tl.n_face * 128, tl.face_dofs);
+          return;
+        }
+      int wi = (int)xcd_block(blockIdx.x, n_march);
       if (a.pair_order != nullptr) // expensive workgroups first (pair_order); a scalar load
         wi = ((const __attribute__((address_space(4))) int *)a.pair_order)[wi];
       const int tx = wi % tl.ntx, ty = (wi / tl.ntx) % tl.nty, zc = wi / (tl.ntx * tl.nty);
       const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
 #ifdef ASM_PAIR_STAMP
-      const bool         stamp_on = tx == tl.ntx / 2 && ty == tl.nty / 2 && zc == tl.nzc / 2 && threadIdx.x < 64;
+#  ifndef ASM_PAIR_STAMP_TILE
+#    define ASM_PAIR_STAMP_TILE 0 // 0: a tile in the middle of the block, 1: at the low x face, 2: at the low x and y faces
+#  endif
+      const bool stamp_on = tx == (ASM_PAIR_STAMP_TILE >= 1 ? 0 : tl.ntx / 2) && ty == (ASM_PAIR_STAMP_TILE >= 2 ? 0 : tl.nty / 2) && zc == tl.nzc / 2 &&
+                            threadIdx.x < 64;
       unsigned long long stamp_t = __builtin_amdgcn_s_memtime(), stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
@@ -1020,8 +1125,8 @@ namespace asmamd
       // (a pure function of the block and the device: computed once per shape)
       struct Key
       {
-        int v[17];
-        bool operator<(const Key &o) const { return std::lexicographical_compare(v, v + 17, o.v, o.v + 17); }
+        int v[20];
+        bool operator<(const Key &o) const { return std::lexicographical_compare(v, v + 20, o.v, o.v + 20); }
       };
       static std::mutex                mtx;
       static std::map<Key, PairTiling> cache;
@@ -1033,6 +1138,7 @@ namespace asmamd
           key.v[6 + d]  = g.ext_lo[d];
           key.v[9 + d]  = g.own_hi[d];
           key.v[12 + d] = g.ext_hi[d];
+          key.v[17 + d] = g.dir_lo[d] * 2 + g.dir_hi[d];
         }
       const char *env = std::getenv("ASM_PAIR_ZCHUNKS");
       key.v[15]       = n_cu_in;
@@ -1085,6 +1191,15 @@ namespace asmamd
         }
       tl.zlen = (g.nc[2] + best - 1) / best;
       tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
+      // workgroups for the Dirichlet planes: eight DoFs per thread, at most one round of compute units' worth
+      tl.face_dofs = 0;
+      for (int d = 0; d < 3; ++d)
+        {
+          const int       d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+          const long long m1 = g.wrap[d1] ? g.nc[d1] * g.p : g.ext_hi[d1] - g.ext_lo[d1] + 1, m2 = g.wrap[d2] ? g.nc[d2] * g.p : g.ext_hi[d2] - g.ext_lo[d2] + 1;
+          tl.face_dofs += (long long)((g.dir_lo[d] ? 1 : 0) + (g.dir_hi[d] ? 1 : 0)) * m1 * m2;
+        }
+      tl.n_face = (int)std::min<long long>((tl.face_dofs + 128 * 8 - 1) / (128 * 8), 2ll * n_cu);
       std::lock_guard<std::mutex> lock(mtx);
       cache[key] = tl;
       return tl;
@@ -1106,7 +1221,7 @@ namespace asmamd
             }
           done.fetch_or(bit, std::memory_order_release);
         }
-      hipLaunchKernelGGL((pair_sweep_kernel<MODE>), dim3(tl.ntx * tl.nty * tl.nzc), dim3(128), L_TOTAL * sizeof(double), st, g, k, a, tl);
+      hipLaunchKernelGGL((pair_sweep_kernel<MODE>), dim3(tl.ntx * tl.nty * tl.nzc + tl.n_face), dim3(128), L_TOTAL * sizeof(double), st, g, k, a, tl);
       return true;
     }
   } // namespace

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["DEALII_ASM_AMD_LIB"] = os.path.join(ROOT, "dealii-asm_amd", "abl", "lib_pairstamp.so")
+os.environ["DEALII_ASM_AMD_LIB"] = os.path.join(ROOT, "dealii-asm_amd", "abl", os.environ.get("PAIR_STAMP_LIB", "lib_pairstamp.so"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_package
 
