@@ -210,6 +210,7 @@ EXPORTED_SYMBOLS = [
     "asm_tiled_plan",
     "asm_pair_plan",
     "asm_pair_sweeps_in_use",
+    "asm_pair_zchunks",
     "asm_mg_coarse_failures",
     "asm_mg_graph_replays",
     "asm_mg_comm_init",
@@ -273,6 +274,7 @@ def load_library():
     lib.asm_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     lib.asm_tiled_laplace_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_pair_sweeps_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.asm_pair_zchunks.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_pair_plan.argtypes = [C.POINTER(AsmParams), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
     lib.asm_vec_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.asm_vec_multi_dot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_double)]
@@ -702,6 +704,12 @@ class Context:
         a, f = C.c_int32(0), C.c_int32(0)
         self._check(self.lib.asm_pair_sweeps_in_use(self.handle, C.byref(a), C.byref(f)))
         return bool(a.value), bool(f.value)
+
+    def pair_zchunks(self):
+        """z chunks of the wave-pair sweeps (0: the schedule model's first choice)"""
+        z = C.c_int32(0)
+        self._check(self.lib.asm_pair_zchunks(self.handle, C.byref(z)))
+        return z.value
 
     def tiled_laplace_rows(self):
         r = C.c_int32()

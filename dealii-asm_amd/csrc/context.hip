@@ -80,6 +80,7 @@ struct asm_ctx
   DevKron                  kron_a{}, kron_p{};
   const int *              order_pair = nullptr; // work order of the wave-pair sweeps (pair_order)
   bool                     pair_a = false, pair_p = false; // which sweeps take the wave-pair kernel (tune_pair)
+  int                      pair_zchunks = 0;               // ... with how many z chunks (0: the schedule model's choice)
   std::vector<void *>      allocs;
   bool                     ras_direct = true; // ASM_RAS_ATOMICS: restricted additive Schwarz through the atomics path on one rank too
   std::vector<double *>    work_pool; // released solver work vectors (asm_work_vector_*), kept until asm_destroy
@@ -605,6 +606,7 @@ namespace
     a.rows   = ctx->laplace_rows;
     a.order  = (a.mode == OP_PLAIN || a.mode == OP_RESIDUAL) ? ctx->order_a : ctx->order_p;
     a.pair_order = ctx->order_pair;
+    a.pair_zchunks = ctx->pair_zchunks;
     if (!ov && ctx->debug_two_phase)
       {
         a.phase = 1;
@@ -1094,6 +1096,17 @@ namespace
         ctx->pair_p = ctx->kron_p.valid && std::atoi(env) != 0;
         return ASM_OK;
       }
+    // the number of z chunks of the pair sweeps: 0 = the schedule model's choice (whose work order the context holds)
+    const auto set_chunks = [&](const int zchunks) -> int {
+      if (zchunks == ctx->pair_zchunks)
+        return ASM_OK;
+      ctx->pair_zchunks = zchunks;
+      if (std::getenv("ASM_NO_TILED_ORDER") != nullptr)
+        return ASM_OK;
+      std::vector<int> order;
+      pair_order(ctx->g, ctx->n_cu, order, zchunks);
+      return upload(ctx, order, &ctx->order_pair);
+    };
     std::array<int, 14> key;
     key[0] = ctx->device;
     for (int d = 0; d < 3; ++d)
@@ -1111,7 +1124,7 @@ namespace
         {
           ctx->pair_a = (hit->second & 1) != 0;
           ctx->pair_p = (hit->second & 2) != 0;
-          return ASM_OK;
+          return set_chunks(hit->second >> 2);
         }
     }
     hipEvent_t e0, e1;
@@ -1120,64 +1133,108 @@ namespace
     // operands that are not all zero (the clock the chip holds, and with it which family is faster, depends on the data)
     {
       const long long gb[3] = {0, 0, 0}, gs[3] = {1 << 20, 1 << 20, 1 << 20};
-      vec_initial_guess(ctx->g, ctx->R, gb, gs, ctx->stream);
       vec_initial_guess(ctx->g, ctx->S, gb, gs, ctx->stream);
+      vec_initial_guess(ctx->g, ctx->T, gb, gs, ctx->stream);
     }
-    // the forms the Chebyshev iteration uses: T = S - A R, T = R + f2 P^-1 S
-    const auto time_of = [&](const bool fdm, const bool pair) -> float {
-      TiledArgs a = fdm ? TiledArgs{PC_STEP1, ctx->S, ctx->T, nullptr, ctx->R, nullptr, 1., 0.5} :
-                          TiledArgs{OP_RESIDUAL, ctx->R, ctx->T, ctx->S, nullptr, nullptr, 0., 0.};
-      a.device     = ctx->device;
-      a.n_cu       = ctx->n_cu;
-      a.rows       = ctx->laplace_rows;
-      a.order      = fdm ? ctx->order_p : ctx->order_a;
-      a.pair_order = ctx->order_pair;
-      const auto launch = [&]() {
-        if (pair)
-          {
-            const bool was_a = ctx->pair_a, was_p = ctx->pair_p;
-            ctx->pair_a = ctx->pair_p = true;
-            const bool ok = fdm ? pair_fdm(ctx, a, ctx->stream) : pair_laplace(ctx, a, ctx->stream);
-            ctx->pair_a   = was_a;
-            ctx->pair_p   = was_p;
-            return ok;
-          }
-        return fdm ? fdm_tiled(ctx->g, ctx->f, a, ctx->stream) : laplace_tiled(ctx->g, ctx->op, a, ctx->stream);
+    // what is timed is the Chebyshev step the sweeps are used in, with its operands (cheb_apply: R = b - A x, then
+    // x += f P^-1 R in place; here x = S, b = T): which kernel is faster depends on what the sweep before it has left in
+    // the caches.  A family without a tiled kernel is left out of the step (and keeps its generic kernel).
+    const bool have_a = ctx->s.laplace_tiled, have_p = ctx->s.fdm_tiled;
+    const auto time_step = [&](const bool pair_a, const bool pair_p) -> float {
+      TiledArgs aa{OP_RESIDUAL, ctx->S, ctx->R, ctx->T, nullptr, nullptr, 0., 0.};
+      TiledArgs ap{PC_STEP1, ctx->R, ctx->S, nullptr, ctx->S, nullptr, 1., 0.05};
+      for (TiledArgs *a : {&aa, &ap})
+        {
+          a->device       = ctx->device;
+          a->n_cu         = ctx->n_cu;
+          a->rows         = ctx->laplace_rows;
+          a->order        = a == &ap ? ctx->order_p : ctx->order_a;
+          a->pair_order   = ctx->order_pair;
+          a->pair_zchunks = ctx->pair_zchunks;
+        }
+      const bool was_a = ctx->pair_a, was_p = ctx->pair_p;
+      ctx->pair_a = ctx->pair_p = true;
+      const auto step           = [&]() {
+        bool ok = true;
+        if (have_a)
+          ok = pair_a ? pair_laplace(ctx, aa, ctx->stream) : laplace_tiled(ctx->g, ctx->op, aa, ctx->stream);
+        if (ok && have_p)
+          ok = pair_p ? pair_fdm(ctx, ap, ctx->stream) : fdm_tiled(ctx->g, ctx->f, ap, ctx->stream);
+        return ok;
       };
       bool ok = true;
       for (int rep = 0; rep < 2 && ok; ++rep)
-        ok = launch();
+        ok = step();
       (void)hipEventRecord(e0, ctx->stream);
-      for (int rep = 0; rep < 6 && ok; ++rep)
-        ok = launch();
+      for (int rep = 0; rep < 5 && ok; ++rep)
+        ok = step();
       (void)hipEventRecord(e1, ctx->stream);
+      ctx->pair_a = was_a;
+      ctx->pair_p = was_p;
       float ms = 1e30f;
       if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)
         ok = false;
       return ok ? ms : 1e30f;
     };
-    // (two interleaved rounds per family, the better of each: a box's clock drifts within the measurement)
-    const auto faster = [&](const bool fdm) {
-      float tp = 1e30f, tt = 1e30f;
+    const bool can_pair_a = ctx->kron_a.valid && ctx->s.laplace_tiled, can_pair_p = ctx->kron_p.valid && ctx->s.fdm_tiled;
+    // the number of z chunks: the schedule model (kernels_pair.hip: schedule) ranks the candidates, but its first ones
+    // differ by less than its error, so they are measured - with the pair kernel for P^-1 where there is one (its main
+    // use), otherwise for A
+    int        err   = ASM_OK;
+    const bool for_p = can_pair_p;
+    if (std::getenv("ASM_PAIR_ZCHUNKS") == nullptr && (can_pair_a || can_pair_p))
+      {
+        std::vector<int> cand;
+        pair_chunk_candidates(ctx->g, ctx->n_cu, cand);
+        std::vector<std::pair<float, int>> timed;
+        for (std::size_t i = 0; i < cand.size() && i < 16 && !err; ++i)
+          if (!(err = set_chunks(cand[i])))
+            timed.emplace_back(time_step(!for_p, for_p), cand[i]);
+        // (the three fastest once more: a box's clock drifts within the measurement)
+        std::sort(timed.begin(), timed.end());
+        int   best      = 0;
+        float best_time = 1e30f;
+        for (std::size_t i = 0; i < timed.size() && i < 3 && !err; ++i)
+          if (!(err = set_chunks(timed[i].second)))
+            {
+              const float t = std::min(timed[i].first, time_step(!for_p, for_p));
+              if (t < best_time)
+                {
+                  best_time = t;
+                  best      = timed[i].second;
+                }
+            }
+        if (!err)
+          err = set_chunks(best);
+      }
+    if (err)
+      {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return err;
+      }
+    // (two interleaved rounds per choice, the better of each)
+    const auto faster = [&](const bool pa1, const bool pp1, const bool pa0, const bool pp0) {
+      float t1 = 1e30f, t0 = 1e30f;
       for (int round = 0; round < 2; ++round)
         {
-          tp = std::min(tp, time_of(fdm, true));
-          tt = std::min(tt, time_of(fdm, false));
+          t1 = std::min(t1, time_step(pa1, pp1));
+          t0 = std::min(t0, time_step(pa0, pp0));
         }
-      return tp < 0.98f * tt;
+      return t1 < 0.985f * t0;
     };
     int pick = 0;
-    if (ctx->kron_a.valid && ctx->s.laplace_tiled)
-      pick |= faster(false) ? 1 : 0;
-    if (ctx->kron_p.valid && ctx->s.fdm_tiled)
-      pick |= faster(true) ? 2 : 0;
+    if (can_pair_p)
+      pick |= faster(false, true, false, false) ? 2 : 0;
+    if (can_pair_a)
+      pick |= faster(true, (pick & 2) != 0, false, (pick & 2) != 0) ? 1 : 0;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ctx->pair_a = (pick & 1) != 0;
     ctx->pair_p = (pick & 2) != 0;
     {
       std::lock_guard<std::mutex> lock(g_tune_mutex);
-      g_pair_cache[key] = pick;
+      g_pair_cache[key] = pick | (ctx->pair_zchunks << 2);
     }
     HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->R, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
@@ -2614,6 +2671,15 @@ asm_pair_sweeps_in_use(const asm_ctx *ctx, int32_t *laplace, int32_t *fdm)
     return ASM_ERR_INVALID_VALUE;
   *laplace = ctx->pair_a ? 1 : 0;
   *fdm     = ctx->pair_p ? 1 : 0;
+  return ASM_OK;
+}
+
+int
+asm_pair_zchunks(const asm_ctx *ctx, int32_t *zchunks)
+{
+  if (!ctx || !zchunks)
+    return ASM_ERR_INVALID_VALUE;
+  *zchunks = ctx->pair_zchunks;
   return ASM_OK;
 }
 

@@ -78,8 +78,9 @@ namespace asmamd
     int rows = 0;
     // single-phase launches: work index of every launch position (tiled_order), or nullptr = the positions themselves
     const int *order = nullptr;
-    // the same for the wave-pair sweep (pair_order)
+    // the same for the wave-pair sweep (pair_order), and its number of z chunks (0: the schedule model's choice)
     const int *pair_order = nullptr;
+    int        pair_zchunks = 0;
   };
   // Work order of a single-phase tiled sweep (device-independent, host side).  The workgroups at Dirichlet faces live
   // up to 1.5 times as long as the others (constrained rows, full-matrix sweeps; profiles/r03_workgroup_trace.txt), and a
@@ -101,9 +102,11 @@ namespace asmamd
   // work order of the pair sweep (host side, device-independent): order[p] = work index (tile x fastest, tile y, z chunk)
   // of launch position p: every XCD keeps its contiguous range of the work but starts with its expensive workgroups (tiles
   // at physical boundaries).  Returns the number of workgroups.
-  int pair_order(const DevGrid &g, int n_cu, std::vector<int> &order);
+  int pair_order(const DevGrid &g, int n_cu, std::vector<int> &order, int zchunks = 0);
+  // chunk counts in the order of the schedule model's estimate (best first): the context measures the first few
+  void pair_chunk_candidates(const DevGrid &g, int n_cu, std::vector<int> &zchunks);
   // the tiling of the pair sweep (host side): out = {tiles x, tiles y, z chunks, layers per chunk, first cell x, first cell y}
-  void pair_plan(const DevGrid &g, int n_cu, int out[6]);
+  void pair_plan(const DevGrid &g, int n_cu, int out[6], int zchunks = 0);
 
   // ---- vector kernels (kernels_vector.hip)
   // elementwise over the whole allocation

@@ -716,6 +716,9 @@ namespace asmamd
         wi = ((const __attribute__((address_space(4))) int *)a.pair_order)[wi];
       const int tx = wi % tl.ntx, ty = (wi / tl.ntx) % tl.nty, zc = wi / (tl.ntx * tl.nty);
       const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
+#ifndef ASM_PAIR_ABL
+#  define ASM_PAIR_ABL 0 // diagnostic builds (wrong results): 1 no plane requests, 2 no diagonal reads, 4 no scratchpad traffic, 8 no arithmetic in the z columns
+#endif
 #ifdef ASM_PAIR_STAMP
 #  ifndef ASM_PAIR_STAMP_TILE
 #    define ASM_PAIR_STAMP_TILE 0 // 0: a tile in the middle of the block, 1: at the low x face, 2: at the low x and y faces
@@ -918,29 +921,38 @@ namespace asmamd
               for (int e = 0; e < NZC; ++e)
                 if (e < NZC - 1 || role == 0)
                   {
-                    if (more)
+                    if (more && !(ASM_PAIR_ABL & 1))
                       plane_request_step<AR::S0, AR::S1>(e, next0, next1, c);
                     double       u0 = t0[e], u1 = n1, u2 = n2, u3 = n3, u4 = n4;
                     const double d0 = nd[0], d1 = nd[1], d2 = nd[2], d3 = nd[3], d4 = nd[4];
                     if (e + 1 < NZC && (e + 1 < NZC - 1 || role == 0))
                       {
-                        n1 = X_z[(0 * NE + e + 1) * 64];
-                        n2 = X_z[(1 * NE + e + 1) * 64];
-                        n3 = X_z[(2 * NE + e + 1) * 64];
-                        n4 = X_z[(3 * NE + e + 1) * 64];
+                        if (!(ASM_PAIR_ABL & 4))
+                          {
+                            n1 = X_z[(0 * NE + e + 1) * 64];
+                            n2 = X_z[(1 * NE + e + 1) * 64];
+                            n3 = X_z[(2 * NE + e + 1) * 64];
+                            n4 = X_z[(3 * NE + e + 1) * 64];
+                          }
+                        if (!(ASM_PAIR_ABL & 2))
+                          {
 #pragma unroll
-                        for (int cc = 0; cc < N1; ++cc)
-                          nd[cc] = Dz[(e + 1) * N1 + cc];
+                            for (int cc = 0; cc < N1; ++cc)
+                              nd[cc] = Dz[(e + 1) * N1 + cc];
+                          }
                       }
                     t0[e] = u4;
-                    line5<true>(u0, u1, u2, u3, u4, qf);
-                    u0 *= d0;
-                    u1 *= d1;
-                    u2 *= d2;
-                    u3 *= d3;
-                    u4 *= d4;
-                    line5<false>(u0, u1, u2, u3, u4, qb);
-                    if (emit)
+                    if (!(ASM_PAIR_ABL & 8))
+                      {
+                        line5<true>(u0, u1, u2, u3, u4, qf);
+                        u0 *= d0;
+                        u1 *= d1;
+                        u2 *= d2;
+                        u3 *= d3;
+                        u4 *= d4;
+                        line5<false>(u0, u1, u2, u3, u4, qb);
+                      }
+                    if (emit && !(ASM_PAIR_ABL & 4))
                       {
                         X_z[(0 * NE + e) * 64] = u0 + carry[e];
                         X_z[(1 * NE + e) * 64] = u1;
@@ -1062,8 +1074,8 @@ namespace asmamd
     }
 
     // ---- host side ------------------------------------------------------------------------------------------------
-    // relative cost of a workgroup's layer: tiles with cells at a physical boundary redo the sweeps of that direction
-    // with the full matrices under lane masks (stage timers: profiles/r04_pair_stamps.txt)
+    // relative cost of a workgroup's layer: tiles with cells at a physical boundary take the sweeps of that direction with
+    // full matrices (stage timers: profiles/r04_pair_stamps.txt)
     double
     tile_cost(const DevGrid &g, const PairTiling &tl, const int tx, const int ty)
     {
@@ -1072,7 +1084,8 @@ namespace asmamd
         const bool lo = !g.wrap[d] && g.ext_lo[d] == 0, hi = !g.wrap[d] && g.own_hi[d] == g.nc[d] * P;
         return (lo && c0 <= 0) || (hi && c0 <= g.nc[d] - 1 && c0 + TX > g.nc[d] - 1);
       };
-      return 1.0 + (at_boundary(0, tx * OX + tl.x_first) ? 0.4 : 0.) + (at_boundary(1, ty * OY + tl.y_first) ? 0.4 : 0.);
+      // (stage timers: +17 % per layer in a tile at a face, about twice that at an edge)
+      return 1.0 + (at_boundary(0, tx * OX + tl.x_first) ? 0.17 : 0.) + (at_boundary(1, ty * OY + tl.y_first) ? 0.17 : 0.);
     }
     int
     chunk_layers(const DevGrid &g, const PairTiling &tl, const int zc)
@@ -1120,7 +1133,7 @@ namespace asmamd
     }
 
     PairTiling
-    make_pair_tiling(const DevGrid &g, const int n_cu_in)
+    make_pair_tiling(const DevGrid &g, const int n_cu_in, const int zchunks = 0, std::vector<int> *ranking = nullptr)
     {
       // (a pure function of the block and the device: computed once per shape)
       struct Key
@@ -1142,13 +1155,14 @@ namespace asmamd
         }
       const char *env = std::getenv("ASM_PAIR_ZCHUNKS");
       key.v[15]       = n_cu_in;
-      key.v[16]       = env != nullptr ? std::atoi(env) : 0;
-      {
-        std::lock_guard<std::mutex> lock(mtx);
-        const auto                  it = cache.find(key);
-        if (it != cache.end())
-          return it->second;
-      }
+      key.v[16]       = env != nullptr ? std::atoi(env) : zchunks;
+      if (ranking == nullptr)
+        {
+          std::lock_guard<std::mutex> lock(mtx);
+          const auto                  it = cache.find(key);
+          if (it != cache.end())
+            return it->second;
+        }
       PairTiling tl;
       const int  n_cu  = n_cu_in > 0 ? n_cu_in : 256;
       const auto first = [&](const int d) { return (g.wrap[d] || g.ext_lo[d] < 0) ? -1 : 0; };
@@ -1172,8 +1186,9 @@ namespace asmamd
         best = std::max(1, std::min(key.v[16], g.nc[2]));
       else
         {
-          double best_end = 1e300;
-          int    last_chunks = 0;
+          double                              best_end = 1e300;
+          int                                 last_chunks = 0;
+          std::vector<std::pair<double, int>> scored;
           for (int nzc = 1; nzc <= g.nc[2]; ++nzc)
             {
               tl.zlen = (g.nc[2] + nzc - 1) / nzc;
@@ -1182,11 +1197,21 @@ namespace asmamd
                 continue;
               last_chunks      = tl.nzc;
               const double end = schedule(g, tl, slots, nullptr);
+              scored.emplace_back(end, tl.nzc);
               if (end < best_end * (1. - 1e-9))
                 {
                   best_end = end;
                   best     = tl.nzc;
                 }
+            }
+          if (ranking != nullptr)
+            {
+              // (the model ranks chunk counts whose schedules end within a few per cent of each other: the context
+              //  measures the first few, context.hip: tune_pair)
+              std::sort(scored.begin(), scored.end());
+              ranking->clear();
+              for (const auto &sc : scored)
+                ranking->push_back(sc.second);
             }
         }
       tl.zlen = (g.nc[2] + best - 1) / best;
@@ -1241,18 +1266,24 @@ namespace asmamd
   }
 #endif
 
-  int
-  pair_order(const DevGrid &g, const int n_cu, std::vector<int> &order)
+  void
+  pair_chunk_candidates(const DevGrid &g, const int n_cu, std::vector<int> &zchunks)
   {
-    const PairTiling tl = make_pair_tiling(g, n_cu);
+    make_pair_tiling(g, n_cu, 0, &zchunks);
+  }
+
+  int
+  pair_order(const DevGrid &g, const int n_cu, std::vector<int> &order, const int zchunks)
+  {
+    const PairTiling tl = make_pair_tiling(g, n_cu, zchunks);
     schedule(g, tl, 2ll * (n_cu > 0 ? n_cu : 256), &order);
     return (int)order.size();
   }
 
   void
-  pair_plan(const DevGrid &g, const int n_cu, int out[6])
+  pair_plan(const DevGrid &g, const int n_cu, int out[6], const int zchunks)
   {
-    const PairTiling tl = make_pair_tiling(g, n_cu);
+    const PairTiling tl = make_pair_tiling(g, n_cu, zchunks);
     out[0]              = tl.ntx;
     out[1]              = tl.nty;
     out[2]              = tl.nzc;
@@ -1269,7 +1300,7 @@ namespace asmamd
     // 32-bit byte offsets inside a DoF plane
     if (g.stride[2] * 8 >= (1ll << 31))
       return false;
-    const PairTiling tl = make_pair_tiling(g, a.n_cu);
+    const PairTiling tl = make_pair_tiling(g, a.n_cu, a.pair_zchunks);
     switch (a.mode)
       {
         case OP_PLAIN: return launch_pair<OP_PLAIN>(g, k, a, tl, st);

@@ -358,6 +358,9 @@ int asm_pair_plan(const asm_params *p, int32_t n_cu, int32_t plan[6], int32_t *o
  * created; ASM_PAIR=1 / 0 fixes it): *laplace, *fdm = 1 / 0.  Replaces the same reference methods as the tiled kernels:
  * LaplaceOperatorMatrixFree::vmult (include/operator.h:1367-1430), ASPoissonPreconditioner::vmult (include/matrix_free.h:1023-1062). */
 int asm_pair_sweeps_in_use(const asm_ctx *ctx, int32_t *laplace, int32_t *fdm);
+/* z chunks of the context's wave-pair sweeps: the schedule model (asm_pair_plan) ranks the chunk counts, the context
+ * measures the first few when it is created; 0 = the model's first choice, ASM_PAIR_ZCHUNKS=n fixes it.  Reported by bench.py. */
+int asm_pair_zchunks(const asm_ctx *ctx, int32_t *zchunks);
 /* Cell rows (waves) per workgroup of the context's tiled Laplace sweep: 8 = first generation, 9 / 10 / 11 = second
  * (picked by a measurement at creation, or ASM_TILED_ROWS); 0 = no tiled Laplace sweep.  Reported by bench.py. */
 int asm_tiled_laplace_rows(const asm_ctx *ctx, int32_t *rows);
