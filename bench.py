@@ -368,7 +368,7 @@ def main():
                 "proc_grid": grid,
                 "kernel_variant": ctx.kernel_variant(),
                 "laplace_rows": ctx.tiled_laplace_rows(),
-                "pair_sweeps": {"laplace": pair_a, "fdm": pair_p, "z_chunks": ctx.pair_zchunks()},
+                "pair_sweeps": {"laplace": pair_a, "fdm": pair_p, "z_chunks": ctx.pair_zchunks(), "waves": ctx.pair_waves()},
                 "lambda_max_estimate": lam,
                 **({"rehearsal": "periodic directions closed by RCCL messages of the rank to itself"} if self_interface else {}),
             },
@@ -410,7 +410,7 @@ def main():
             out["north_star_point"] = {"cells": list(NORTH_STAR_CELLS), "n_dofs": ns.n_dofs, "steps": ns_steps,
                                        "ms_per_step": el / ns_steps * 1e3, "value": ns.n_dofs * ns_steps / el, "unit": "DoF/s",
                                        "laplace_rows": ns.tiled_laplace_rows(),
-                                       "pair_sweeps": dict(zip(("laplace", "fdm", "z_chunks"), ns.pair_sweeps() + (ns.pair_zchunks(),))), "kernels": nk}
+                                       "pair_sweeps": dict(zip(("laplace", "fdm", "z_chunks", "waves"), ns.pair_sweeps() + (ns.pair_zchunks(), ns.pair_waves()))), "kernels": nk}
             ns.close()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, pkg, cells)

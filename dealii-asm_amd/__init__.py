@@ -211,6 +211,7 @@ EXPORTED_SYMBOLS = [
     "asm_pair_plan",
     "asm_pair_sweeps_in_use",
     "asm_pair_zchunks",
+    "asm_pair_waves",
     "asm_mg_coarse_failures",
     "asm_mg_graph_replays",
     "asm_mg_comm_init",
@@ -275,6 +276,7 @@ def load_library():
     lib.asm_tiled_laplace_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_pair_sweeps_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.asm_pair_zchunks.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.asm_pair_waves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_pair_plan.argtypes = [C.POINTER(AsmParams), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
     lib.asm_vec_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.asm_vec_multi_dot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_double)]
@@ -710,6 +712,12 @@ class Context:
         z = C.c_int32(0)
         self._check(self.lib.asm_pair_zchunks(self.handle, C.byref(z)))
         return z.value
+
+    def pair_waves(self):
+        """waves per tile of the wave-pair sweeps (4 or 2)"""
+        w = C.c_int32(0)
+        self._check(self.lib.asm_pair_waves(self.handle, C.byref(w)))
+        return w.value
 
     def tiled_laplace_rows(self):
         r = C.c_int32()

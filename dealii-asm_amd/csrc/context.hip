@@ -81,6 +81,7 @@ struct asm_ctx
   const int *              order_pair = nullptr; // work order of the wave-pair sweeps (pair_order)
   bool                     pair_a = false, pair_p = false; // which sweeps take the wave-pair kernel (tune_pair)
   int                      pair_zchunks = 0;               // ... with how many z chunks (0: the schedule model's choice)
+  int                      pair_waves = 0;                 // ... and waves per tile (2, or 0 / 4: four where the update has them)
   std::vector<void *>      allocs;
   bool                     ras_direct = true; // ASM_RAS_ATOMICS: restricted additive Schwarz through the atomics path on one rank too
   std::vector<double *>    work_pool; // released solver work vectors (asm_work_vector_*), kept until asm_destroy
@@ -607,6 +608,7 @@ namespace
     a.order  = (a.mode == OP_PLAIN || a.mode == OP_RESIDUAL) ? ctx->order_a : ctx->order_p;
     a.pair_order = ctx->order_pair;
     a.pair_zchunks = ctx->pair_zchunks;
+    a.pair_waves   = ctx->pair_waves;
     if (!ov && ctx->debug_two_phase)
       {
         a.phase = 1;
@@ -1123,8 +1125,9 @@ namespace
       if (hit != g_pair_cache.end())
         {
           ctx->pair_a = (hit->second & 1) != 0;
-          ctx->pair_p = (hit->second & 2) != 0;
-          return set_chunks(hit->second >> 2);
+          ctx->pair_p     = (hit->second & 2) != 0;
+          ctx->pair_waves = (hit->second & 4) != 0 ? 2 : 0;
+          return set_chunks(hit->second >> 3);
         }
     }
     hipEvent_t e0, e1;
@@ -1151,6 +1154,7 @@ namespace
           a->order        = a == &ap ? ctx->order_p : ctx->order_a;
           a->pair_order   = ctx->order_pair;
           a->pair_zchunks = ctx->pair_zchunks;
+          a->pair_waves   = ctx->pair_waves;
         }
       const bool was_a = ctx->pair_a, was_p = ctx->pair_p;
       ctx->pair_a = ctx->pair_p = true;
@@ -1184,26 +1188,36 @@ namespace
     const bool for_p = can_pair_p;
     if (std::getenv("ASM_PAIR_ZCHUNKS") == nullptr && (can_pair_a || can_pair_p))
       {
+        // ... for both forms of the kernel (four and two waves per tile) unless ASM_PAIR_WAVES names one
         std::vector<int> cand;
         pair_chunk_candidates(ctx->g, ctx->n_cu, cand);
-        std::vector<std::pair<float, int>> timed;
-        for (std::size_t i = 0; i < cand.size() && i < 16 && !err; ++i)
-          if (!(err = set_chunks(cand[i])))
-            timed.emplace_back(time_step(!for_p, for_p), cand[i]);
+        const char *                                       env_w = std::getenv("ASM_PAIR_WAVES");
+        std::vector<std::pair<float, std::pair<int, int>>> timed;
+        for (const int waves : {4, 2})
+          if (env_w == nullptr || std::atoi(env_w) == waves)
+            for (std::size_t i = 0; i < cand.size() && i < 16 && !err; ++i)
+              if (!(err = set_chunks(cand[i])))
+                {
+                  ctx->pair_waves = waves;
+                  timed.emplace_back(time_step(!for_p, for_p), std::make_pair(cand[i], waves));
+                }
         // (the three fastest once more: a box's clock drifts within the measurement)
         std::sort(timed.begin(), timed.end());
-        int   best      = 0;
+        int   best = 0, best_waves = 0;
         float best_time = 1e30f;
         for (std::size_t i = 0; i < timed.size() && i < 3 && !err; ++i)
-          if (!(err = set_chunks(timed[i].second)))
+          if (!(err = set_chunks(timed[i].second.first)))
             {
-              const float t = std::min(timed[i].first, time_step(!for_p, for_p));
+              ctx->pair_waves = timed[i].second.second;
+              const float t   = std::min(timed[i].first, time_step(!for_p, for_p));
               if (t < best_time)
                 {
-                  best_time = t;
-                  best      = timed[i].second;
+                  best_time  = t;
+                  best       = timed[i].second.first;
+                  best_waves = timed[i].second.second;
                 }
             }
+        ctx->pair_waves = best_waves;
         if (!err)
           err = set_chunks(best);
       }
@@ -1234,7 +1248,7 @@ namespace
     ctx->pair_p = (pick & 2) != 0;
     {
       std::lock_guard<std::mutex> lock(g_tune_mutex);
-      g_pair_cache[key] = pick | (ctx->pair_zchunks << 2);
+      g_pair_cache[key] = pick | (ctx->pair_waves == 2 ? 4 : 0) | (ctx->pair_zchunks << 3);
     }
     HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->R, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
@@ -2680,6 +2694,15 @@ asm_pair_zchunks(const asm_ctx *ctx, int32_t *zchunks)
   if (!ctx || !zchunks)
     return ASM_ERR_INVALID_VALUE;
   *zchunks = ctx->pair_zchunks;
+  return ASM_OK;
+}
+
+int
+asm_pair_waves(const asm_ctx *ctx, int32_t *waves)
+{
+  if (!ctx || !waves)
+    return ASM_ERR_INVALID_VALUE;
+  *waves = ctx->pair_waves == 2 ? 2 : 4;
   return ASM_OK;
 }
 

@@ -81,6 +81,7 @@ namespace asmamd
     // the same for the wave-pair sweep (pair_order), and its number of z chunks (0: the schedule model's choice)
     const int *pair_order = nullptr;
     int        pair_zchunks = 0;
+    int        pair_waves   = 0; // waves per tile of the wave-pair sweep: 2, or 0 / 4 = four where the mode has them
   };
   // Work order of a single-phase tiled sweep (device-independent, host side).  The workgroups at Dirichlet faces live
   // up to 1.5 times as long as the others (constrained rows, full-matrix sweeps; profiles/r03_workgroup_trace.txt), and a

@@ -16,7 +16,12 @@
 //     conflict-free, no address arithmetic), each wave takes 13 / 12 of the 25 z columns through the z sweeps and the
 //     diagonal in place in the scratchpad, and transforms two of the four output planes back (planes 2r, 2r + 1; the
 //     contributions of two consecutive cells of a column to their common plane are added BEFORE the back transform:
-//     4 instead of 5 plane transforms each way).  Three barriers of two waves per layer, each wave alone on its SIMD.
+//     4 instead of 5 plane transforms each way).  Two barriers of two waves per layer, each wave alone on its SIMD.
+//   * ... or FOUR waves per tile (NW = 4, every mode but the three-term update): wave r transforms plane 1 + r, takes
+//     7 / 6 / 6 / 6 z columns and transforms output plane r back.  A wave then needs half the registers (one plane and one
+//     operand plane in flight: 128 + 128), two waves share a SIMD, and one wave's scratchpad writes, requests and waits
+//     overlap the other's arithmetic: alone on its SIMD a wave executes instructions 47 % of the time (SQ counters,
+//     profiles/r04_pair_design.txt).
 //   * Nothing is parked in registers, so the accumulation registers are free: they take the NEXT layer's source planes
 //     and update operands, requested a whole layer ahead by plain global loads into FIXED registers the compiler never
 //     sees (one wave per SIMD has no other wave to hide a miss behind).  Audit of every build: no v_accvgpr_* outside
@@ -44,7 +49,12 @@ namespace asmamd
   {
     constexpr int P = 4, N1 = 5, NE = 25;
     constexpr int TX = 8, TY = 8, OX = TX - 1, OY = TY - 1;
-    constexpr int NZC = 13; // z columns of wave 0 (0..12); wave 1 takes 13..24
+    // z columns of wave 0 of NW waves (0..12 of two, 0..6 of four); the others take one less each: 13..24, or 7..12, 13..18, 19..24
+    constexpr int
+    z_columns(const int nw)
+    {
+      return nw == 2 ? 13 : 7;
+    }
 
     // LDS of a workgroup (doubles)
     constexpr int L_X    = P * NE * 64;                                // scratchpad: slot (q, e) of lane l at (q * 25 + e) * 64 + l
@@ -60,6 +70,8 @@ namespace asmamd
     // vmcnt as well and complete out of order - the kernel's wait counts assume that no flat instruction exists (audit)
     typedef __attribute__((address_space(3))) double       *lds_ptr;
     typedef const __attribute__((address_space(3))) double *lds_cptr;
+    typedef __attribute__((address_space(1))) double       *glb_ptr;
+    typedef __attribute__((address_space(1))) dbl2_u       *glb_dbl2_ptr;
 
     struct PairTiling
     {
@@ -274,12 +286,31 @@ namespace asmamd
     struct Lane
     {
       unsigned flags;
-      unsigned srow8[N1]; // source: byte offset of DoF row j of the cell inside a plane (cells not computed: cell 0)
-      unsigned sd4;       // ... and the step from column 0 to column 4 (periodic seam), bytes
-      unsigned orow8[P];  // operands / dst: byte offset of DoF row j of the DoFs the lane owns
+      // source: byte offset of DoF row 0 and row 4 of the cell inside a plane (cells not computed: cell 0), rows 1..3 follow
+      // row 0 at the row stride (row 4 may lie behind a periodic seam), and the step from column 0 to column 4 (seam)
+      unsigned srow0, srow4, sd4;
+      // operands / dst: byte offset of row 0 of the DoFs the lane owns and the step to the next row (0: only row 0 exists)
+      unsigned orow0, ostep;
+      unsigned sstep; // the row stride in bytes (wave-uniform, kept with the rest)
       __device__ __forceinline__ bool is(const unsigned f) const { return (flags & f) != 0u; }
       // (the tests are made again in every layer instead of being kept as lane masks over the march)
       __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(flags)); }
+      // the offsets are formed where they are used, from values the compiler cannot trace: it would otherwise keep all
+      // rows' offsets, their seam variants and zero-extended copies over the march - registers a wave of four per tile lacks
+      template <int J>
+      __device__ __forceinline__ unsigned srow() const
+      {
+        unsigned b = J == 4 ? srow4 : srow0;
+        asm volatile("" : "+v"(b));
+        return J == 4 || J == 0 ? b : b + (unsigned)J * sstep;
+      }
+      template <int J>
+      __device__ __forceinline__ unsigned orow() const
+      {
+        unsigned b = orow0;
+        asm volatile("" : "+v"(b));
+        return J == 0 ? b : b + (unsigned)J * ostep;
+      }
     };
 
     // The x and y matrices of a lane (its cell's classes) in LDS: [F^T 30][B 30][F even-odd 16][B even-odd 16].
@@ -295,7 +326,7 @@ namespace asmamd
       const double *gx, *gy; // the tables of the x / y classes in global memory: [class][KRON_MAT_STRIDE]
     };
     // one sweep direction of a plane
-    template <bool FWD, bool XDIR, bool LDSFULL>
+    template <bool FWD, bool XDIR, bool LDSFULL, bool FULLREGS>
     __device__ __forceinline__ void
     sweep_dir(double (&v)[NE], const XYMatrices &m, const Lane &c)
     {
@@ -307,9 +338,18 @@ namespace asmamd
           else
             sweep_y<FWD>(v, q);
         }
-      else if (LDSFULL)
+      else if (LDSFULL && FULLREGS)
         {
           const FullRegs q((XDIR ? m.mx : m.my) + (FWD ? 0 : 30));
+          if (XDIR)
+            sweep_x<FWD>(v, q);
+          else
+            sweep_y<FWD>(v, q);
+        }
+      else if (LDSFULL)
+        {
+          // (four waves per tile: a wave has no 50 registers for the matrix; its rows come from LDS line by line)
+          const FullCoef q((XDIR ? m.mx : m.my) + (FWD ? 0 : 30));
           if (XDIR)
             sweep_x<FWD>(v, q);
           else
@@ -348,19 +388,19 @@ namespace asmamd
         }
     }
     // x-y transform of one plane v[j * 5 + i]: forward x then y with F, backward y then x with B
-    template <bool FWD, bool LDSFULL>
+    template <bool FWD, bool LDSFULL, bool FULLREGS>
     __device__ __forceinline__ void
     plane2d(double (&v)[NE], const XYMatrices &m, const Lane &c)
     {
       if (FWD)
         {
-          sweep_dir<true, true, LDSFULL>(v, m, c);
-          sweep_dir<true, false, LDSFULL>(v, m, c);
+          sweep_dir<true, true, LDSFULL, FULLREGS>(v, m, c);
+          sweep_dir<true, false, LDSFULL, FULLREGS>(v, m, c);
         }
       else
         {
-          sweep_dir<false, false, LDSFULL>(v, m, c);
-          sweep_dir<false, true, LDSFULL>(v, m, c);
+          sweep_dir<false, false, LDSFULL, FULLREGS>(v, m, c);
+          sweep_dir<false, true, LDSFULL, FULLREGS>(v, m, c);
         }
     }
 
@@ -373,29 +413,49 @@ namespace asmamd
     //   a[A_P0 .. +49]                   the prologue's plane 0: the registers of the operands requested after it
     // The three-term update leaves the compiler a0..a27, the other modes a0..a91.
     // ---------------------------------------------------------------------------------------------------------------
-    template <bool NEED_B>
+    template <bool NEED_B, int NW>
     struct ARegs
     {
       static constexpr int BASE = NEED_B ? 28 : 92;
       static constexpr int S0 = BASE, S1 = BASE + 50, XA0 = BASE + 100, XA1 = BASE + 132, XB0 = NEED_B ? BASE + 164 : 0, XB1 = NEED_B ? BASE + 196 : 0;
       static constexpr int P0 = NEED_B ? XB0 : XA0;
+      static constexpr int T0 = 0, CY = 0; // (two waves per tile: in arithmetic registers)
       static_assert((NEED_B ? XB1 : XA1) + 32 == 256 && P0 + 50 <= 256, "accumulation register map");
+    };
+    // four waves per tile: one source plane and one operand plane per wave, in the 128 accumulation registers two waves
+    // per SIMD leave each of them; the prologue's plane goes through the source plane's registers.  The compiler has a0..a17.
+    template <>
+    struct ARegs<false, 4>
+    {
+      static constexpr int BASE = 18;
+      // (the z sweeps' carried values - plane 4 of the layer below in transformed space, and the contributions to plane 0 of
+      //  the layer above - of this wave's 7 columns live here too: 128 arithmetic registers do not hold them over the march)
+      static constexpr int T0 = BASE, CY = BASE + 14;
+      static constexpr int S0 = BASE + 28, S1 = S0, XA0 = S0 + 50, XA1 = XA0, XB0 = 0, XB1 = 0;
+      static constexpr int P0 = S0;
+      static_assert(XA0 + 32 == 128, "accumulation register map");
     };
 #define ASM_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
     // (makes the kernel's register count cover the fixed registers; the statement itself does nothing)
+    template <int NW>
     __device__ __forceinline__ void
     areg_reserve()
     {
-      asm volatile("" ::: ASM_A10(10), ASM_A10(11), ASM_A10(12), ASM_A10(13), ASM_A10(14), ASM_A10(15), ASM_A10(16), ASM_A10(17), ASM_A10(18),
-                   ASM_A10(19), ASM_A10(20), ASM_A10(21), ASM_A10(22), ASM_A10(23), ASM_A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
+      if (NW == 2)
+        asm volatile("" ::: ASM_A10(10), ASM_A10(11), ASM_A10(12), ASM_A10(13), ASM_A10(14), ASM_A10(15), ASM_A10(16), ASM_A10(17), ASM_A10(18),
+                     ASM_A10(19), ASM_A10(20), ASM_A10(21), ASM_A10(22), ASM_A10(23), ASM_A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
+      else
+        asm volatile("" ::: ASM_A10(5), ASM_A10(6), ASM_A10(7), ASM_A10(8), ASM_A10(9), ASM_A10(10), ASM_A10(11), "a120", "a121", "a122", "a123", "a124",
+                     "a125", "a126", "a127");
     }
 #undef ASM_A10
 
     // five values of DoF row J: x 0..3 from the row's offset, x 4 from its own (periodic seam)
     template <int A0, int J>
     __device__ __forceinline__ void
-    plane_request_row(const double *plane, const unsigned o, const unsigned o4)
+    plane_request_row(const double *plane, const unsigned o, const unsigned d4)
     {
+      const unsigned o4 = o + d4;
       // (s_nop: the base may just have come back from a vector lane - v_readlane writes the scalar register, and a vector
       //  memory instruction that reads a scalar register a VALU instruction wrote needs 5 wait states in between; the
       //  compiler pads for that hazard everywhere except in front of an asm statement, whose content it does not know)
@@ -432,6 +492,25 @@ namespace asmamd
       asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(lo), "=v"(hi) : "n"(A), "n"(A + 1));
       return __hiloint2double(hi, lo);
     }
+    template <int A>
+    __device__ __forceinline__ void
+    areg_set(const double x)
+    {
+      asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(__double2loint(x)), "v"(__double2hiint(x)), "n"(A), "n"(A + 1));
+    }
+    // f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>): loops whose index names a register
+    template <typename F, int... I>
+    __device__ __forceinline__ void
+    static_for_impl(F &&f, std::integer_sequence<int, I...>)
+    {
+      (f(std::integral_constant<int, I>{}), ...);
+    }
+    template <int N, typename F>
+    __device__ __forceinline__ void
+    static_for(F &&f)
+    {
+      static_for_impl(f, std::make_integer_sequence<int, N>());
+    }
     template <int A0, int... E>
     __device__ __forceinline__ void
     aregs_to(double *v, std::integer_sequence<int, E...>)
@@ -453,20 +532,20 @@ namespace asmamd
     __device__ __forceinline__ void
     plane_request(const double *plane, const Lane &c)
     {
-      plane_request_row<A0, 0>(plane, c.srow8[0], c.srow8[0] + c.sd4);
-      plane_request_row<A0, 1>(plane, c.srow8[1], c.srow8[1] + c.sd4);
-      plane_request_row<A0, 2>(plane, c.srow8[2], c.srow8[2] + c.sd4);
-      plane_request_row<A0, 3>(plane, c.srow8[3], c.srow8[3] + c.sd4);
-      plane_request_row<A0, 4>(plane, c.srow8[4], c.srow8[4] + c.sd4);
+      plane_request_row<A0, 0>(plane, c.srow<0>(), c.sd4);
+      plane_request_row<A0, 1>(plane, c.srow<1>(), c.sd4);
+      plane_request_row<A0, 2>(plane, c.srow<2>(), c.sd4);
+      plane_request_row<A0, 3>(plane, c.srow<3>(), c.sd4);
+      plane_request_row<A0, 4>(plane, c.srow<4>(), c.sd4);
     }
     template <int A0>
     __device__ __forceinline__ void
     operand_request(const double *plane, const Lane &c)
     {
-      operand_request_row<A0, 0>(plane, c.orow8[0]);
-      operand_request_row<A0, 1>(plane, c.orow8[1]);
-      operand_request_row<A0, 2>(plane, c.orow8[2]);
-      operand_request_row<A0, 3>(plane, c.orow8[3]);
+      operand_request_row<A0, 0>(plane, c.orow<0>());
+      operand_request_row<A0, 1>(plane, c.orow<1>());
+      operand_request_row<A0, 2>(plane, c.orow<2>());
+      operand_request_row<A0, 3>(plane, c.orow<3>());
     }
 
     // constrained DoFs of a source plane read as zero (whole plane: a Dirichlet plane in z)
@@ -490,25 +569,28 @@ namespace asmamd
         }
     }
 
-    // one tenth of the requests of the next layer's two planes (step 0..9 = plane step / 5, row step % 5): spread over
+    // one tenth of the requests of the next layer's two planes (step 0..9 = plane step / 5, row step % 5; 0..4 with one
+    // plane per wave): spread over
     // the z columns instead of issued in one burst, which the vector memory path accepts at 60 cycles per request
     // (stage timers, profiles/r04_pair_stamps.txt)
-    template <int AS0, int AS1>
+    template <int AS0, int AS1, int PPW>
     __device__ __forceinline__ void
     plane_request_step(const int step, const double *p0, const double *p1, const Lane &c)
     {
+      if (PPW == 1 && step >= 5)
+        return;
       switch (step)
         {
-          case 0: plane_request_row<AS0, 0>(p0, c.srow8[0], c.srow8[0] + c.sd4); break;
-          case 1: plane_request_row<AS0, 1>(p0, c.srow8[1], c.srow8[1] + c.sd4); break;
-          case 2: plane_request_row<AS0, 2>(p0, c.srow8[2], c.srow8[2] + c.sd4); break;
-          case 3: plane_request_row<AS0, 3>(p0, c.srow8[3], c.srow8[3] + c.sd4); break;
-          case 4: plane_request_row<AS0, 4>(p0, c.srow8[4], c.srow8[4] + c.sd4); break;
-          case 5: plane_request_row<AS1, 0>(p1, c.srow8[0], c.srow8[0] + c.sd4); break;
-          case 6: plane_request_row<AS1, 1>(p1, c.srow8[1], c.srow8[1] + c.sd4); break;
-          case 7: plane_request_row<AS1, 2>(p1, c.srow8[2], c.srow8[2] + c.sd4); break;
-          case 8: plane_request_row<AS1, 3>(p1, c.srow8[3], c.srow8[3] + c.sd4); break;
-          case 9: plane_request_row<AS1, 4>(p1, c.srow8[4], c.srow8[4] + c.sd4); break;
+          case 0: plane_request_row<AS0, 0>(p0, c.srow<0>(), c.sd4); break;
+          case 1: plane_request_row<AS0, 1>(p0, c.srow<1>(), c.sd4); break;
+          case 2: plane_request_row<AS0, 2>(p0, c.srow<2>(), c.sd4); break;
+          case 3: plane_request_row<AS0, 3>(p0, c.srow<3>(), c.sd4); break;
+          case 4: plane_request_row<AS0, 4>(p0, c.srow<4>(), c.sd4); break;
+          case 5: plane_request_row<AS1, 0>(p1, c.srow<0>(), c.sd4); break;
+          case 6: plane_request_row<AS1, 1>(p1, c.srow<1>(), c.sd4); break;
+          case 7: plane_request_row<AS1, 2>(p1, c.srow<2>(), c.sd4); break;
+          case 8: plane_request_row<AS1, 3>(p1, c.srow<3>(), c.sd4); break;
+          case 9: plane_request_row<AS1, 4>(p1, c.srow<4>(), c.sd4); break;
           default: break;
         }
     }
@@ -518,7 +600,7 @@ namespace asmamd
     {
       static constexpr bool need_a = (MODE == OP_RESIDUAL || MODE == PC_STEP1 || MODE == PC_UPDATE);
       static constexpr bool need_b = (MODE == PC_UPDATE);
-      static constexpr int  n_operand_requests = (need_a ? 16 : 0) + (need_b ? 16 : 0); // per wave and layer
+      static constexpr int  n_operand_requests = (need_a ? 8 : 0) + (need_b ? 8 : 0); // per output plane
     };
     template <int MODE>
     __device__ __forceinline__ double
@@ -547,7 +629,7 @@ namespace asmamd
     // fused update and store of DoF row J of a plane: the operands come out of the accumulation registers row by row
     template <int MODE, int J, int AXA, int AXB>
     __device__ __forceinline__ void
-    emit_row(const TiledArgs &a, const Lane &c, double *__restrict__ dplane, const double (&o)[NE])
+    emit_row(const TiledArgs &a, const Lane &c, const glb_ptr dplane, const double (&o)[NE])
     {
       using MT = ModeTraits<MODE>;
       if (J == 0 ? !c.is(F_YD0) : !c.is(F_PH_Y))
@@ -557,7 +639,10 @@ namespace asmamd
             aregs_to<AXA + 8 * J>(xa, std::make_integer_sequence<int, P>());
           if (MT::need_b)
             aregs_to<AXB + 8 * J>(xb, std::make_integer_sequence<int, P>());
-          double *const d = (double *)((char *)dplane + c.orow8[J]);
+          // (the offset's zero extension must happen here, next to the stores: extended ahead of the loop - as the compiler
+          //  likes to - it costs a register pair per row and a 64-bit vector add instead of the scalar-base address form)
+          const unsigned off = c.orow<J>();
+          const glb_ptr d = (glb_ptr)((__attribute__((address_space(1))) char *)dplane + off);
           dbl2          lo, hi;
           lo.x = fused_update<MODE>(a, o[J * 5 + 0], xa[0], xb[0]);
           lo.y = fused_update<MODE>(a, o[J * 5 + 1], xa[1], xb[1]);
@@ -571,12 +656,12 @@ namespace asmamd
           else if (c.is(F_XD0))
             {
               __builtin_nontemporal_store(lo.y, d + 1);
-              __builtin_nontemporal_store(hi, (dbl2_u *)(d + 2));
+              __builtin_nontemporal_store(hi, (glb_dbl2_ptr)(d + 2));
             }
           else
             {
-              __builtin_nontemporal_store(lo, (dbl2_u *)d);
-              __builtin_nontemporal_store(hi, (dbl2_u *)(d + 2));
+              __builtin_nontemporal_store(lo, (glb_dbl2_ptr)d);
+              __builtin_nontemporal_store(hi, (glb_dbl2_ptr)(d + 2));
             }
         }
     }
@@ -608,10 +693,13 @@ namespace asmamd
         }
       if (c.is(F_OWNER) && !plane_constrained)
         {
-          emit_row<MODE, 0, AXA, AXB>(a, c, dplane, o);
-          emit_row<MODE, 1, AXA, AXB>(a, c, dplane, o);
-          emit_row<MODE, 2, AXA, AXB>(a, c, dplane, o);
-          emit_row<MODE, 3, AXA, AXB>(a, c, dplane, o);
+          // (scalar base + the row's 32-bit offset: see Lane::refresh; the pointer keeps its address space through the asm)
+          glb_ptr dp = (glb_ptr)dplane;
+          asm volatile("" : "+s"(dp));
+          emit_row<MODE, 0, AXA, AXB>(a, c, dp, o);
+          emit_row<MODE, 1, AXA, AXB>(a, c, dp, o);
+          emit_row<MODE, 2, AXA, AXB>(a, c, dp, o);
+          emit_row<MODE, 3, AXA, AXB>(a, c, dp, o);
         }
     }
 
@@ -619,7 +707,10 @@ namespace asmamd
     __device__ __forceinline__ long long
     plane_offset(const DevGrid &g, const int K)
     {
-      return g.store_index_near(2, K) * g.stride[2];
+      // (wave-uniform, but the compiler computes it on the vector unit when it runs short of scalar registers - and would
+      //  then hand the asm requests a vector register pair as their scalar base)
+      const long long o = g.store_index_near(2, K) * g.stride[2];
+      return ((long long)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)o);
     }
 
 #ifdef ASM_PAIR_STAMP
@@ -696,25 +787,35 @@ namespace asmamd
     }
 
     // ---------------------------------------------------------------------------------------------------------------
-    template <int MODE>
-    __global__ void __launch_bounds__(128) pair_sweep_kernel(const DevGrid g, const DevKron kr, const TiledArgs a, const PairTiling tl)
+    // NW = waves per tile: 2 (one wave per SIMD, 256 + 256 registers) or 4 (two waves per SIMD, 128 + 128)
+    template <int MODE, int NW>
+    __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
+    pair_sweep_kernel(const DevGrid g, const DevKron kr, const TiledArgs a, const PairTiling tl)
     {
       extern __shared__ __attribute__((aligned(16))) double lds[];
       using MT = ModeTraits<MODE>;
-      using AR = ARegs<MT::need_b>;
+      using AR = ARegs<MT::need_b, NW>;
+      static_assert(NW == 2 || (NW == 4 && !MT::need_b), "four waves per tile: not for the three-term update");
       constexpr bool LDSFULL = !MT::need_b; // (see XYMatrices)
+      constexpr bool FULLREGS = NW == 2;
+      constexpr int  PPW     = 4 / NW;      // planes per wave and stage
+      constexpr int  NZC     = z_columns(NW);
+      constexpr int  NT      = 64 * NW;
       // workgroups b and b + 8 land on the same XCD: contiguous ranges of the work per XCD (L2 locality of neighbouring tiles)
       const int n_march = tl.ntx * tl.nty * tl.nzc;
       if ((int)blockIdx.x >= n_march)
         {
           // (the last workgroups of the launch: the Dirichlet planes)
-          constrained_dofs<MODE>(g, a, ((long long)blockIdx.x - n_march) * 128 + threadIdx.x, (long long)tl.n_face * 128, tl.face_dofs);
+          constrained_dofs<MODE>(g, a, ((long long)blockIdx.x - n_march) * NT + threadIdx.x, (long long)tl.n_face * NT, tl.face_dofs);
           return;
         }
       int wi = (int)xcd_block(blockIdx.x, n_march);
       if (a.pair_order != nullptr) // expensive workgroups first (pair_order); a scalar load
         wi = ((const __attribute__((address_space(4))) int *)a.pair_order)[wi];
-      const int tx = wi % tl.ntx, ty = (wi / tl.ntx) % tl.nty, zc = wi / (tl.ntx * tl.nty);
+      // (integer division runs on the vector unit even for wave-uniform values: back to scalar registers explicitly, or
+      //  everything derived from the chunk index - the plane addresses the asm requests take as scalar operands - stays there)
+      const int tx = __builtin_amdgcn_readfirstlane(wi % tl.ntx), ty = __builtin_amdgcn_readfirstlane((wi / tl.ntx) % tl.nty),
+                zc = __builtin_amdgcn_readfirstlane(wi / (tl.ntx * tl.nty));
       const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
 #ifndef ASM_PAIR_ABL
 #  define ASM_PAIR_ABL 0 // diagnostic builds (wrong results): 1 no plane requests, 2 no diagonal reads, 4 no scratchpad traffic, 8 no arithmetic in the z columns
@@ -729,7 +830,7 @@ namespace asmamd
 #endif
 
       const int lane = threadIdx.x & 63, cl = lane % TX, rw = lane / TX;
-      const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 / 1, wave-uniform
+      const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 .. NW - 1, wave-uniform
       const int cx = X0 + cl, cy = Y0 + rw;
       Lane      c;
       int       clx = 0, cly = 0;
@@ -753,15 +854,14 @@ namespace asmamd
         const int sx = cell_xy ? cx : 0, sy = cell_xy ? cy : 0;
         const int x0 = g.store_index_near(0, P * sx);
         c.sd4        = (unsigned)(g.store_index_near(0, P * sx + P) - x0) * 8u;
-#pragma unroll
-        for (int j = 0; j < N1; ++j)
-          c.srow8[j] = (unsigned)(g.store_index_near(1, P * sy + j) * (int)g.stride[1] + x0) * 8u;
+        c.sstep      = (unsigned)g.stride[1] * 8u;
+        c.srow0      = (unsigned)(g.store_index_near(1, P * sy) * (int)g.stride[1] + x0) * 8u;
+        c.srow4      = (unsigned)(g.store_index_near(1, P * sy + P) * (int)g.stride[1] + x0) * 8u;
         // owned rows: rows 1..3 of a cell that only owns row 0 do not exist
         const int ox = owner ? cx : 0, oy = owner ? cy : 0;
         const int xo = g.store_index_near(0, P * ox);
-#pragma unroll
-        for (int j = 0; j < P; ++j)
-          c.orow8[j] = (unsigned)(g.store_index_near(1, P * oy + ((owner && ph_y) ? 0 : j)) * (int)g.stride[1] + xo) * 8u;
+        c.orow0      = (unsigned)(g.store_index_near(1, P * oy) * (int)g.stride[1] + xo) * 8u;
+        c.ostep      = (owner && ph_y) ? 0u : c.sstep;
         if (cell_xy)
           {
             clx = kr.cls[0][cx + 1];
@@ -773,9 +873,9 @@ namespace asmamd
       const lds_ptr Dl = (lds_ptr)lds + L_X;
       const lds_ptr Zl = Dl + L_D;
       const lds_ptr Ml = Zl + L_ZERO;
-      for (int e = threadIdx.x; e < L_M; e += 128)
+      for (int e = threadIdx.x; e < L_M; e += NT)
         Ml[e] = kr.mat[e];
-      for (int e = threadIdx.x; e < L_ZERO; e += 128)
+      for (int e = threadIdx.x; e < L_ZERO; e += NT)
         Zl[e] = 0.;
       XYMatrices mxy;
       mxy.mx = Ml + (0 * KRON_MAX_CLS + clx) * KRON_MAT_STRIDE;
@@ -791,26 +891,55 @@ namespace asmamd
         mxy.gy      = kr.mat + 1 * KRON_MAX_CLS * KRON_MAT_STRIDE;
       }
       // this lane's diagonal: column e of this wave at Dz + 5 e (cells that are not computed: zeros)
-      const int      col0 = NZC * role;
+      const int      col0 = role == 0 ? 0 : NZC + (role - 1) * (NZC - 1);
       const lds_cptr Dz   = cell_xy ? Dl + (cly * KRON_MAX_CLS + clx) * KRON_DIAG_STRIDE + col0 * N1 : Zl;
 
       // scratchpad addresses of this lane: forward planes of this wave, its z columns, its backward planes
-      const lds_ptr X_fwd = Xl + (2 * role) * NE * 64;
+      const lds_ptr X_fwd = Xl + (PPW * role) * NE * 64;
       const lds_ptr X_z   = Xl + col0 * 64;
-      const lds_ptr X_bwd = Xl + (2 * role) * NE * 64;
-      const int     kf = 1 + 2 * role, kb = 2 * role; // first forward / backward plane of this wave
+      const lds_ptr X_bwd = Xl + (PPW * role) * NE * 64;
+      const int     kf = 1 + PPW * role, kb = PPW * role; // first forward / backward plane of this wave
 
       const int Zb = zc * tl.zlen, Ze = min(Zb + tl.zlen, g.nc[2]);
       const int z_first = cell_computable(g, 2, Zb - 1) ? Zb - 1 : Zb;
 
       const double *const opA = (MODE == OP_RESIDUAL) ? a.b : a.x;
 
-      double t0[NZC], carry[NZC];
-#pragma unroll
-      for (int e = 0; e < NZC; ++e)
-        carry[e] = 0.;
+      // carried by the z sweeps, per column of this wave: plane 4 of the layer below in transformed space (t0) and the
+      // layer below's contribution to this layer's plane 0 (carry); NW = 4: in accumulation registers
+      constexpr bool CARRY_AREGS = NW == 4;
+      double         t0[CARRY_AREGS ? 1 : NZC], carry[CARRY_AREGS ? 1 : NZC];
+      const auto     t0_get = [&](auto ec) -> double {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (CARRY_AREGS)
+          return areg_double<AR::T0 + 2 * e>();
+        else
+          return t0[e];
+      };
+      const auto t0_set = [&](auto ec, const double x) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (CARRY_AREGS)
+          areg_set<AR::T0 + 2 * e>(x);
+        else
+          t0[e] = x;
+      };
+      const auto carry_get = [&](auto ec) -> double {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (CARRY_AREGS)
+          return areg_double<AR::CY + 2 * e>();
+        else
+          return carry[e];
+      };
+      const auto carry_set = [&](auto ec, const double x) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (CARRY_AREGS)
+          areg_set<AR::CY + 2 * e>(x);
+        else
+          carry[e] = x;
+      };
 
-      areg_reserve();
+      areg_reserve<NW>();
+      static_for<NZC>([&](auto ec) { carry_set(ec, 0.); });
       __syncthreads(); // tables in LDS
       int clz_cached = -1;
       // the z classes: this layer's was loaded a layer ago; which of them have an even-odd form
@@ -823,25 +952,33 @@ namespace asmamd
       {
         const long long z0 = plane_offset(g, P * z_first);
         plane_request<AR::P0>(a.src + z0, c);
-        plane_request<AR::S0>(a.src + plane_offset(g, P * z_first + kf), c);
-        plane_request<AR::S1>(a.src + plane_offset(g, P * z_first + kf + 1), c);
+        if (PPW == 2)
+          {
+            plane_request<AR::S0>(a.src + plane_offset(g, P * z_first + kf), c);
+            plane_request<AR::S1>(a.src + plane_offset(g, P * z_first + kf + 1), c);
+          }
         vm_wait<0>();
         double v[NE];
         plane_unpack<AR::P0>(v);
+        // (one plane per wave: the prologue's plane came through the registers of the first layer's plane)
+        if (PPW == 1)
+          plane_request<AR::S0>(a.src + plane_offset(g, P * z_first + kf), c);
         if (kr.mask_constrained)
           mask_source(v, c, g.dirichlet(2, P * z_first));
         // (the first operands go into registers the prologue's plane occupied)
         if (MT::need_a && z_first >= Zb)
           {
             operand_request<AR::XA0>(opA + plane_offset(g, P * z_first + kb), c);
-            operand_request<AR::XA1>(opA + plane_offset(g, P * z_first + kb + 1), c);
+            if (PPW == 2)
+              operand_request<AR::XA1>(opA + plane_offset(g, P * z_first + kb + 1), c);
           }
         if (MT::need_b && z_first >= Zb)
           {
             operand_request<AR::XB0>(a.x_old + plane_offset(g, P * z_first + kb), c);
-            operand_request<AR::XB1>(a.x_old + plane_offset(g, P * z_first + kb + 1), c);
+            if (PPW == 2)
+              operand_request<AR::XB1>(a.x_old + plane_offset(g, P * z_first + kb + 1), c);
           }
-        plane2d<true, LDSFULL>(v, mxy, c);
+        plane2d<true, LDSFULL, FULLREGS>(v, mxy, c);
         if (role == 0)
           {
 #pragma unroll
@@ -849,9 +986,10 @@ namespace asmamd
               Xl[e * 64] = v[e];
           }
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < NZC; ++e)
-          t0[e] = (e < NZC - 1 || role == 0) ? X_z[e * 64] : 0.;
+        static_for<NZC>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          t0_set(ec, (e < NZC - 1 || role == 0) ? X_z[e * 64] : 0.);
+        });
         __syncthreads();
       }
 
@@ -866,8 +1004,13 @@ namespace asmamd
           if (clz != clz_cached)
             {
               // (the scratchpad barriers below order these writes against the reads of the layer before)
+              // (rare - first layer, boundary layers: a rolled loop over an index the compiler cannot trace, or it keeps the
+              //  unrolled copies' addresses in registers over the whole march)
               const double *src = kr.diag + (long long)clz * L_D;
-              for (int e = threadIdx.x; e < L_D; e += 128)
+              int           e0  = threadIdx.x;
+              asm volatile("" : "+v"(e0));
+#pragma unroll 1
+              for (int e = e0; e < L_D; e += NT)
                 Dl[e] = src[e];
               clz_cached = clz;
             }
@@ -877,28 +1020,29 @@ namespace asmamd
             if (cz == z_first || cz == Zb || MT::n_operand_requests == 0)
               vm_wait<0>(); // first layers of a chunk, or nothing but the stores of the layer below is younger
             else
-              vm_wait<MT::n_operand_requests>(); // younger than the plane requests: the operand requests of this layer
+              vm_wait<PPW * MT::n_operand_requests>(); // younger than the plane requests: the operand requests of this layer
             PSTAMP(7);
             {
               double v[NE];
               plane_unpack<AR::S0>(v);
               if (kr.mask_constrained)
-                mask_source(v, c, false); // (planes 1..3 of a layer are never Dirichlet planes)
-              plane2d<true, LDSFULL>(v, mxy, c);
+                mask_source(v, c, g.dirichlet(2, P * cz + kf)); // (only plane 4 of a layer can be a Dirichlet plane)
+              plane2d<true, LDSFULL, FULLREGS>(v, mxy, c);
 #pragma unroll
               for (int e = 0; e < NE; ++e)
                 X_fwd[(0 * NE + e) * 64] = v[e];
             }
-            {
-              double v[NE];
-              plane_unpack<AR::S1>(v);
-              if (kr.mask_constrained)
-                mask_source(v, c, g.dirichlet(2, P * cz + kf + 1));
-              plane2d<true, LDSFULL>(v, mxy, c);
+            if (PPW == 2)
+              {
+                double v[NE];
+                plane_unpack<AR::S1>(v);
+                if (kr.mask_constrained)
+                  mask_source(v, c, g.dirichlet(2, P * cz + kf + 1));
+                plane2d<true, LDSFULL, FULLREGS>(v, mxy, c);
 #pragma unroll
-              for (int e = 0; e < NE; ++e)
-                X_fwd[(1 * NE + e) * 64] = v[e];
-            }
+                for (int e = 0; e < NE; ++e)
+                  X_fwd[(1 * NE + e) * 64] = v[e];
+              }
             PSTAMP(8);
           }
           // the next layer's planes are requested a whole layer ahead, one row per z column below
@@ -917,13 +1061,13 @@ namespace asmamd
             for (int cc = 0; cc < N1; ++cc)
               nd[cc] = Dz[cc];
             const auto columns = [&](const auto &qf, const auto &qb) {
-#pragma unroll
-              for (int e = 0; e < NZC; ++e)
+              static_for<NZC>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
                 if (e < NZC - 1 || role == 0)
                   {
                     if (more && !(ASM_PAIR_ABL & 1))
-                      plane_request_step<AR::S0, AR::S1>(e, next0, next1, c);
-                    double       u0 = t0[e], u1 = n1, u2 = n2, u3 = n3, u4 = n4;
+                      plane_request_step<AR::S0, AR::S1, PPW>(e, next0, next1, c);
+                    double       u0 = t0_get(ec), u1 = n1, u2 = n2, u3 = n3, u4 = n4;
                     const double d0 = nd[0], d1 = nd[1], d2 = nd[2], d3 = nd[3], d4 = nd[4];
                     if (e + 1 < NZC && (e + 1 < NZC - 1 || role == 0))
                       {
@@ -941,7 +1085,7 @@ namespace asmamd
                               nd[cc] = Dz[(e + 1) * N1 + cc];
                           }
                       }
-                    t0[e] = u4;
+                    t0_set(ec, u4);
                     if (!(ASM_PAIR_ABL & 8))
                       {
                         line5<true>(u0, u1, u2, u3, u4, qf);
@@ -954,13 +1098,14 @@ namespace asmamd
                       }
                     if (emit && !(ASM_PAIR_ABL & 4))
                       {
-                        X_z[(0 * NE + e) * 64] = u0 + carry[e];
+                        X_z[(0 * NE + e) * 64] = u0 + carry_get(ec);
                         X_z[(1 * NE + e) * 64] = u1;
                         X_z[(2 * NE + e) * 64] = u2;
                         X_z[(3 * NE + e) * 64] = u3;
                       }
-                    carry[e] = u4;
+                    carry_set(ec, u4);
                   }
+              });
             };
             if (eo_z)
               columns(EoCoef(mz + 60), EoCoef(mz + 76));
@@ -985,12 +1130,14 @@ namespace asmamd
               for (int e = 0; e < NE; ++e)
                 w[e] = X_bwd[(0 * NE + e) * 64];
               PSTAMP(9);
+              // (no barrier before the next layer's planes go to the scratchpad: a wave writes the slots it has just read
+              //  itself - output plane q and new plane q + 1 share slot q -, and a wave's LDS operations execute in order)
               if (cz == Zb || !more)
                 vm_wait<0>();
               else
-                vm_wait<30>(); // younger than the operand requests: the 30 plane requests of this layer
+                vm_wait<PPW * 15>(); // younger than the operand requests: the plane requests of this layer
               PSTAMP(10);
-              plane2d<false, LDSFULL>(w, mxy, c);
+              plane2d<false, LDSFULL, FULLREGS>(w, mxy, c);
               emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo0, w, con0);
               // (the next layer's operands of this plane: its registers are free)
               if (more)
@@ -1001,38 +1148,41 @@ namespace asmamd
                     operand_request<AR::XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
                 }
               PSTAMP(11);
-#pragma unroll
-              for (int e = 0; e < NE; ++e)
-                w[e] = X_bwd[(1 * NE + e) * 64];
-              PSTAMP(12);
-              __syncthreads(); // the scratchpad may take the next layer's planes
-              PSTAMP(13);
-              plane2d<false, LDSFULL>(w, mxy, c);
-              emit_plane<MODE, AR::XA1, AR::XB1>(a, c, a.dst + zo1, w, false);
-              if (more)
+              if (PPW == 2)
                 {
-                  if (MT::need_a)
-                    operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
-                  if (MT::need_b)
-                    operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+#pragma unroll
+                  for (int e = 0; e < NE; ++e)
+                    w[e] = X_bwd[(1 * NE + e) * 64];
+                  PSTAMP(12);
+                  PSTAMP(13);
+                  plane2d<false, LDSFULL, FULLREGS>(w, mxy, c);
+                  emit_plane<MODE, AR::XA1, AR::XB1>(a, c, a.dst + zo1, w, false);
+                  if (more)
+                    {
+                      if (MT::need_a)
+                        operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                      if (MT::need_b)
+                        operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                    }
                 }
               PSTAMP(14);
             }
           else
             {
-              __syncthreads();
               if (more)
                 {
                   // halo layer: the update operands of the first owned layer
                   if (MT::need_a)
                     {
                       operand_request<AR::XA0>(opA + plane_offset(g, P * (cz + 1) + kb), c);
-                      operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                      if (PPW == 2)
+                        operand_request<AR::XA1>(opA + plane_offset(g, P * (cz + 1) + kb + 1), c);
                     }
                   if (MT::need_b)
                     {
                       operand_request<AR::XB0>(a.x_old + plane_offset(g, P * (cz + 1) + kb), c);
-                      operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
+                      if (PPW == 2)
+                        operand_request<AR::XB1>(a.x_old + plane_offset(g, P * (cz + 1) + kb + 1), c);
                     }
                 }
             }
@@ -1050,10 +1200,11 @@ namespace asmamd
         {
           // top plane of the block: what the last layer left in the carries of both waves, transformed back by wave 0
           __syncthreads();
-#pragma unroll
-          for (int e = 0; e < NZC; ++e)
+          static_for<NZC>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
             if (e < NZC - 1 || role == 0)
-              X_z[e * 64] = carry[e];
+              X_z[e * 64] = carry_get(ec);
+          });
           __syncthreads();
           if (role == 0 && !g.dirichlet(2, P * g.nc[2]))
             {
@@ -1067,7 +1218,7 @@ namespace asmamd
               if (MT::need_b)
                 operand_request<AR::XB0>(a.x_old + zo, c);
               vm_wait<0>();
-              plane2d<false, LDSFULL>(v, mxy, c);
+              plane2d<false, LDSFULL, FULLREGS>(v, mxy, c);
               emit_plane<MODE, AR::XA0, AR::XB0>(a, c, a.dst + zo, v, false);
             }
         }
@@ -1230,7 +1381,7 @@ namespace asmamd
       return tl;
     }
 
-    template <int MODE>
+    template <int MODE, int NW>
     bool
     launch_pair(const DevGrid &g, const DevKron &k, const TiledArgs &a, const PairTiling &tl, hipStream_t st)
     {
@@ -1238,7 +1389,7 @@ namespace asmamd
       const unsigned long long               bit = 1ull << (a.device & 63);
       if (!(done.load(std::memory_order_acquire) & bit))
         {
-          if (hipFuncSetAttribute((const void *)pair_sweep_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+          if (hipFuncSetAttribute((const void *)pair_sweep_kernel<MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(L_TOTAL * sizeof(double))) != hipSuccess)
             {
               (void)hipGetLastError();
@@ -1246,8 +1397,24 @@ namespace asmamd
             }
           done.fetch_or(bit, std::memory_order_release);
         }
-      hipLaunchKernelGGL((pair_sweep_kernel<MODE>), dim3(tl.ntx * tl.nty * tl.nzc + tl.n_face), dim3(128), L_TOTAL * sizeof(double), st, g, k, a, tl);
+      hipLaunchKernelGGL((pair_sweep_kernel<MODE, NW>), dim3(tl.ntx * tl.nty * tl.nzc + tl.n_face), dim3(64 * NW), L_TOTAL * sizeof(double), st, g, k, a,
+                         tl);
       return true;
+    }
+    // four waves per tile unless the mode or the caller (TiledArgs::pair_waves, ASM_PAIR_WAVES) says otherwise
+    template <int MODE>
+    bool
+    launch_pair(const DevGrid &g, const DevKron &k, const TiledArgs &a, const PairTiling &tl, hipStream_t st)
+    {
+      static const int env_waves = [] {
+        const char *e = std::getenv("ASM_PAIR_WAVES");
+        return e != nullptr ? std::atoi(e) : 0;
+      }();
+      const int waves = env_waves != 0 ? env_waves : a.pair_waves;
+      if constexpr (!ModeTraits<MODE>::need_b)
+        if (waves != 2)
+          return launch_pair<MODE, 4>(g, k, a, tl, st);
+      return launch_pair<MODE, 2>(g, k, a, tl, st);
     }
   } // namespace
 

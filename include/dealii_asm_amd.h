@@ -361,6 +361,9 @@ int asm_pair_sweeps_in_use(const asm_ctx *ctx, int32_t *laplace, int32_t *fdm);
 /* z chunks of the context's wave-pair sweeps: the schedule model (asm_pair_plan) ranks the chunk counts, the context
  * measures the first few when it is created; 0 = the model's first choice, ASM_PAIR_ZCHUNKS=n fixes it.  Reported by bench.py. */
 int asm_pair_zchunks(const asm_ctx *ctx, int32_t *zchunks);
+/* waves per tile of the context's wave-pair sweeps: 4 (two waves per SIMD, 128 + 128 registers each) or 2 (one wave per
+ * SIMD); measured with the chunk counts, ASM_PAIR_WAVES=2|4 fixes it.  The three-term update always runs with 2. */
+int asm_pair_waves(const asm_ctx *ctx, int32_t *waves);
 /* Cell rows (waves) per workgroup of the context's tiled Laplace sweep: 8 = first generation, 9 / 10 / 11 = second
  * (picked by a measurement at creation, or ASM_TILED_ROWS); 0 = no tiled Laplace sweep.  Reported by bench.py. */
 int asm_tiled_laplace_rows(const asm_ctx *ctx, int32_t *rows);

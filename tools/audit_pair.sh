@@ -1,7 +1,8 @@
 #!/bin/bash
 # Audit of the wave-pair kernels (dealii-asm_amd/csrc/kernels_pair.hip): they keep the next layer's planes and operands in
 # FIXED accumulation registers a28..a255 the compiler does not know about.  That is only sound while the compiler itself
-# (a) uses no scratch memory and (b) touches no accumulation register from a28 (three-term update) / a92 (other modes) upwards, (c) emits no flat_ instruction.  Run after every edit of the file.
+# (a) uses no scratch memory and (b) touches no accumulation register from a28 (three-term update) / a92 (other modes, two
+# waves per tile) / a18 (four waves per tile, which also must fit 256 registers) upwards, (c) emits no flat_ instruction.  Run after every edit of the file.
 set -e
 cd "$(dirname "$0")/../dealii-asm_amd"
 out=$(mktemp -d)
@@ -27,11 +28,14 @@ for m in re.finditer(r'^(_ZN6asmamd\S*pair_sweep_kernel\S*):[^\n]*\n(.*?)s_endpg
         return int(mm.group(1)) if mm else -1
     scratch = setval('private_seg_size')
     vg = '%d+%d' % (setval('num_vgpr'), setval('num_agpr'))
-    mode = int(re.search(r'pair_sweep_kernelILi(\d)', name).group(1))
-    limit = 28 if mode == 5 else 92  # ARegs<NEED_B>::BASE
+    mode, waves = (int(x) for x in re.search(r'pair_sweep_kernelILi(\d)ELi(\d)', name).groups())
+    limit = 18 if waves == 4 else (28 if mode == 5 else 92)  # ARegs<NEED_B, NW>::BASE
+    regs = setval('num_vgpr') + setval('num_agpr')
+    if waves == 4 and regs > 256:  # two waves per SIMD
+        limit = -1
     ok = scratch == 0 and worst < limit and 'flat_' not in body
     bad += 0 if ok else 1
-    print('%-4s %s: scratch %d B, vgpr+agpr %s, compiler accvgpr ops %d (highest a%d)' % ('ok' if ok else 'FAIL', re.search(r'pair_sweep_kernelILi(\d)', name).group(0), scratch, vg, n, worst))
+    print('%-4s %s: scratch %d B, vgpr+agpr %s, compiler accvgpr ops %d (highest a%d)' % ('ok' if ok else 'FAIL', re.search(r'pair_sweep_kernelILi(\d)ELi(\d)', name).group(0), scratch, vg, n, worst))
 sys.exit(1 if bad else 0)
 PY
 rm -rf $out

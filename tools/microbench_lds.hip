@@ -6,6 +6,7 @@
 // (s_memtime of wave 0 of workgroup 0) with every compute unit loaded (512 workgroups) and with one workgroup alone.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -27,7 +28,16 @@ __global__ void __launch_bounds__(128) lds_kernel(double *out, const double *in,
   for (int i = 0; i < 8; ++i)
     acc[i] = in[threadIdx.x + 128 + i];
   v4u r[NR > 0 ? NR : 1];
+  v2u q[NR > 0 ? NR : 1];
+#pragma unroll
+  for (int k = 0; k < (NR > 0 ? NR : 1); ++k)
+    {
+      r[k] = v4u{0u, 0u, 0u, 0u};
+      q[k] = v2u{0u, 0u};
+    }
   v4u w = {1u, 2u, 3u, 4u};
+  // (the operand loads have completed before the clock is read: the compiler may reuse their base registers for it)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 4" ::"v"(a), "v"(b), "v"(acc[0]), "v"(acc[7]));
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it)
     {
@@ -39,11 +49,7 @@ __global__ void __launch_bounds__(128) lds_kernel(double *out, const double *in,
           else if (KIND == 1)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[k]) : "v"(base), "n"(1024 * k));
           else
-            {
-              v2u t;
-              asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t) : "v"(base), "n"(512 * k));
-              r[k].x = t.x;
-            }
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[k]) : "v"(base), "n"(512 * k));
         }
 #pragma unroll
       for (int rep = 0; rep < NF / 8; ++rep)
@@ -64,6 +70,12 @@ __global__ void __launch_bounds__(128) lds_kernel(double *out, const double *in,
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR + NW < 16 ? NR + NW : 15));
     }
   asm volatile("s_waitcnt lgkmcnt(0)");
+  // (the reads' destination registers stay allocated until the wait above: the compiler takes an asm output for
+  //  available at once and would otherwise reuse the unused parts of a destination for, e.g., the address of `out`
+  //  while the read is still in flight - the first version of this file faulted that way)
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+    asm volatile("" : "+v"(r[k]), "+v"(q[k]));
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   double                   s = 0.;
 #pragma unroll
@@ -71,7 +83,7 @@ __global__ void __launch_bounds__(128) lds_kernel(double *out, const double *in,
     s += acc[i];
 #pragma unroll
   for (int k = 0; k < NR; ++k)
-    s += (double)r[k].x;
+    s += (double)r[k].x + (double)q[k].x;
   out[blockIdx.x * 128 + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0)
     cyc[0] = t1 - t0;
@@ -90,7 +102,12 @@ run(const char *what, double *out, const double *in, unsigned long long *cyc)
     {
       lds_kernel<NR, NW, NF, KIND><<<blocks, 128, lds>>>(out, in, iters, cyc);
       lds_kernel<NR, NW, NF, KIND><<<blocks, 128, lds>>>(out, in, iters, cyc);
-      hipDeviceSynchronize();
+      if (hipDeviceSynchronize() != hipSuccess)
+        {
+          printf("%s: kernel failed\n", what);
+          fflush(stdout);
+          exit(1);
+        }
       unsigned long long c = 0;
       hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost);
       res[k++] = (double)c / iters;
@@ -98,6 +115,7 @@ run(const char *what, double *out, const double *in, unsigned long long *cyc)
   const double bytes = (KIND == 0 ? 1024. : KIND == 1 ? 1024. : 512.) * (NR + NW);
   printf("%-44s reads %d writes %d fma %2d: %7.1f cycles/iteration loaded (%5.1f B/clk per CU from 4 waves), %7.1f alone\n", what, NR, NW, NF, res[0],
          4. * bytes / res[0], res[1]);
+  fflush(stdout);
 }
 
 int
