@@ -1142,7 +1142,8 @@ namespace
     // what is timed is the Chebyshev step the sweeps are used in, with its operands (cheb_apply: R = b - A x, then
     // x += f P^-1 R in place; here x = S, b = T): which kernel is faster depends on what the sweep before it has left in
     // the caches.  A family without a tiled kernel is left out of the step (and keeps its generic kernel).
-    const bool have_a = ctx->s.laplace_tiled, have_p = ctx->s.fdm_tiled;
+    // (a context with another preconditioner - the diagonal one of a multigrid level - has no FDM tables)
+    const bool have_a = ctx->s.laplace_tiled, have_p = ctx->s.fdm_tiled && ctx->s.prm.precond_type == ASM_PRECOND_FDM;
     const auto time_step = [&](const bool pair_a, const bool pair_p) -> float {
       TiledArgs aa{OP_RESIDUAL, ctx->S, ctx->R, ctx->T, nullptr, nullptr, 0., 0.};
       TiledArgs ap{PC_STEP1, ctx->R, ctx->S, nullptr, ctx->S, nullptr, 1., 0.05};
@@ -1180,7 +1181,7 @@ namespace
         ok = false;
       return ok ? ms : 1e30f;
     };
-    const bool can_pair_a = ctx->kron_a.valid && ctx->s.laplace_tiled, can_pair_p = ctx->kron_p.valid && ctx->s.fdm_tiled;
+    const bool can_pair_a = ctx->kron_a.valid && ctx->s.laplace_tiled, can_pair_p = ctx->kron_p.valid && have_p;
     // the number of z chunks: the schedule model (kernels_pair.hip: schedule) ranks the candidates, but its first ones
     // differ by less than its error, so they are measured - with the pair kernel for P^-1 where there is one (its main
     // use), otherwise for A
@@ -1615,7 +1616,7 @@ asm_create(const asm_params *p, asm_ctx **out)
         if (err)
           return fail(err);
       }
-    if (use_pair && s.fdm_tiled && build_kron_fdm(s, hk))
+    if (use_pair && s.fdm_tiled && s.prm.precond_type == ASM_PRECOND_FDM && build_kron_fdm(s, hk))
       {
         err = up_kron(hk, ctx->kron_p);
         if (err)

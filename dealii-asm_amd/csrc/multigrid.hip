@@ -1312,7 +1312,8 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
     return code;
   };
   const std::vector<LevelSpec> specs = level_sequence(*fine, mp);
-  if (mp.coarse_solver == ASM_MG_COARSE_AUTO)
+  const bool                   coarse_auto = mp.coarse_solver == ASM_MG_COARSE_AUTO;
+  if (coarse_auto)
     {
       // the dense inverse where level 0 is small enough for it (a linear V-cycle, no host synchronisation inside), else CG
       long long n0 = 1;
@@ -1427,13 +1428,23 @@ asm_mg_create(const asm_params *fine, const asm_mg_params *mp_in, asm_mg **out)
           lv.pass_x  = lv.pass_xy + n_xy;
         }
     }
+  // (ASM_MG_COARSE_AUTO falls back to CG where the dense inverse does not exist: a singular level operator - pure Neumann
+  //  problem -, a coarsest level shared by several ranks)
   if (mp.coarse_solver == ASM_MG_COARSE_DIRECT && mg->levels[0].distributed)
-    return fail(ASM_ERR_NOT_SUPPORTED, "direct coarse-grid solver: the coarsest level of a multi-rank hierarchy must be a level of its own");
+    {
+      if (!coarse_auto)
+        return fail(ASM_ERR_NOT_SUPPORTED, "direct coarse-grid solver: the coarsest level of a multi-rank hierarchy must be a level of its own");
+      mp.coarse_solver = mg->mp.coarse_solver = ASM_MG_COARSE_CG;
+    }
   if (mp.coarse_solver == ASM_MG_COARSE_DIRECT)
     {
       std::string error;
       if (const int err = build_coarse_inverse(mg, error))
-        return fail(err, error);
+        {
+          if (!coarse_auto)
+            return fail(err, error);
+          mp.coarse_solver = mg->mp.coarse_solver = ASM_MG_COARSE_CG;
+        }
     }
   // hipGraph of the small levels' legs (one rank; the coarse CG synchronises with the host and cannot be captured):
   // everything from the highest level of at most 2^20 stored DoFs down, if that is below the finest level.

@@ -408,7 +408,8 @@ enum asm_mg_coarse
   ASM_MG_COARSE_CG       = 1, /* Jacobi-preconditioned CG to a relative tolerance (in place of AMG) */
   ASM_MG_COARSE_DIRECT   = 2, /* dense inverse of the level operator, built at creation (levels of <= 2048 DoFs): one
                                * kernel per coarse solve and a linear V-cycle, also in place of AMG */
-  ASM_MG_COARSE_AUTO     = 3  /* default: DIRECT where the coarsest level has at most 2048 DoFs, CG otherwise (a CG coarse solve
+  ASM_MG_COARSE_AUTO     = 3  /* default: DIRECT where the coarsest level has at most 2048 DoFs and its operator a dense inverse
+                               * (not: pure Neumann problem, level shared by several ranks), CG otherwise (a CG coarse solve
                                * makes the V-cycle a non-linear preconditioner and synchronises with the host every iteration) */
 };
 
