@@ -313,13 +313,15 @@ def main():
         key = f"{args.workload}:{cells[0]}x{cells[1]}x{cells[2]}:{ctx.kernel_variant()}:{args.what}:{args.degree}"
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if world == 1 and key in tr:
-                traffic, traffic_src = tr[key][dom], tr[key]["source"]
         except OSError:
-            pass
+            tr = {}
         pair_a, pair_p = ctx.pair_sweeps()
         lap_variant = "generic" if args.workload == "kershaw" else ("wave-pair" if pair_a else ctx.kernel_variant())
         fdm_variant = "wave-pair" if pair_p else ctx.kernel_variant()
+        # (entries per kernel family: the context picks the family per sweep)
+        dom_key = f"{dom}:{lap_variant if dom == 'laplace' else fdm_variant}"
+        if world == 1 and key in tr and dom_key in tr[key]:
+            traffic, traffic_src = tr[key][dom_key], tr[key]["source"]
         # the deformed-cell Laplace sweep is bound by fp64 issue, not by memory (report the FLOP rate then)
         fp64_bound = args.workload == "kershaw" and dom == "laplace"
         if fp64_bound:

@@ -1092,10 +1092,13 @@ namespace
     ctx->pair_a = ctx->pair_p = false;
     if (!ctx->kron_a.valid && !ctx->kron_p.valid)
       return ASM_OK;
+    // ASM_PAIR = 0: tiled kernels, 1: pair kernels for both sweeps, 2: for P^-1 only, 3: for A only - no measurement
+    // (ASM_PAIR_ZCHUNKS, ASM_PAIR_WAVES pin the rest: profiles of exactly the kernels a context had picked)
     if (const char *env = std::getenv("ASM_PAIR"))
       {
-        ctx->pair_a = ctx->kron_a.valid && std::atoi(env) != 0;
-        ctx->pair_p = ctx->kron_p.valid && std::atoi(env) != 0;
+        const int v = std::atoi(env);
+        ctx->pair_a = ctx->kron_a.valid && (v == 1 || v == 3);
+        ctx->pair_p = ctx->kron_p.valid && (v == 1 || v == 2);
         return ASM_OK;
       }
     // the number of z chunks of the pair sweeps: 0 = the schedule model's choice (whose work order the context holds)
@@ -2694,7 +2697,8 @@ asm_pair_zchunks(const asm_ctx *ctx, int32_t *zchunks)
 {
   if (!ctx || !zchunks)
     return ASM_ERR_INVALID_VALUE;
-  *zchunks = ctx->pair_zchunks;
+  const char *env = std::getenv("ASM_PAIR_ZCHUNKS");
+  *zchunks        = env != nullptr ? std::atoi(env) : ctx->pair_zchunks;
   return ASM_OK;
 }
 
@@ -2703,7 +2707,8 @@ asm_pair_waves(const asm_ctx *ctx, int32_t *waves)
 {
   if (!ctx || !waves)
     return ASM_ERR_INVALID_VALUE;
-  *waves = ctx->pair_waves == 2 ? 2 : 4;
+  const char *env = std::getenv("ASM_PAIR_WAVES");
+  *waves          = (env != nullptr ? std::atoi(env) : ctx->pair_waves) == 2 ? 2 : 4;
   return ASM_OK;
 }
 
