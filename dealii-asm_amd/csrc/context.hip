@@ -1094,6 +1094,8 @@ namespace
       return ASM_OK;
     // ASM_PAIR = 0: tiled kernels, 1: pair kernels for both sweeps, 2: for P^-1 only, 3: for A only - no measurement
     // (ASM_PAIR_ZCHUNKS, ASM_PAIR_WAVES pin the rest: profiles of exactly the kernels a context had picked)
+    if (const char *env = std::getenv("ASM_PAIR_WAVES"))
+      ctx->pair_waves = std::atoi(env) == 2 ? 2 : 0;
     if (const char *env = std::getenv("ASM_PAIR"))
       {
         const int v = std::atoi(env);
@@ -2707,8 +2709,7 @@ asm_pair_waves(const asm_ctx *ctx, int32_t *waves)
 {
   if (!ctx || !waves)
     return ASM_ERR_INVALID_VALUE;
-  const char *env = std::getenv("ASM_PAIR_WAVES");
-  *waves          = (env != nullptr ? std::atoi(env) : ctx->pair_waves) == 2 ? 2 : 4;
+  *waves = ctx->pair_waves == 2 ? 2 : 4;
   return ASM_OK;
 }
 

@@ -1411,18 +1411,14 @@ namespace asmamd
                          tl);
       return true;
     }
-    // four waves per tile unless the mode or the caller (TiledArgs::pair_waves, ASM_PAIR_WAVES) says otherwise
+    // four waves per tile unless the mode or the caller (TiledArgs::pair_waves: the context's measurement or ASM_PAIR_WAVES
+    // when it was created) says otherwise
     template <int MODE>
     bool
     launch_pair(const DevGrid &g, const DevKron &k, const TiledArgs &a, const PairTiling &tl, hipStream_t st)
     {
-      static const int env_waves = [] {
-        const char *e = std::getenv("ASM_PAIR_WAVES");
-        return e != nullptr ? std::atoi(e) : 0;
-      }();
-      const int waves = env_waves != 0 ? env_waves : a.pair_waves;
       if constexpr (!ModeTraits<MODE>::need_b)
-        if (waves != 2)
+        if (a.pair_waves != 2)
           return launch_pair<MODE, 4>(g, k, a, tl, st);
       return launch_pair<MODE, 2>(g, k, a, tl, st);
     }

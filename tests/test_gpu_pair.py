@@ -109,6 +109,50 @@ def test_full_size_pair_equals_tiled(pkg, monkeypatch, nc, periodic, degree):
     assert rel(out[1], out[0]) < TOL
 
 
+@pytest.mark.parametrize("waves", [2, 4])
+@pytest.mark.parametrize("zchunks", [1, 2, 5, 64])
+@pytest.mark.parametrize("nc,bc", [((9, 15, 5), "dirichlet"), ((16, 9, 9), "periodic"), ((8, 7, 6), ["neumann", "dirichlet", "periodic"])])
+def test_pair_forms_and_chunkings(pkg, force_pair, monkeypatch, nc, bc, waves, zchunks):
+    """both forms of the kernel (two / four waves per tile; a context otherwise measures and picks one) with pinned z
+    chunkings from one chunk to one layer per chunk: every fused update through a Chebyshev step of degree 3"""
+    monkeypatch.setenv("ASM_PAIR_WAVES", str(waves))
+    monkeypatch.setenv("ASM_PAIR_ZCHUNKS", str(zchunks))
+    mesh, ctx = make_pair(pkg, nc, 4, bc, kernel="tiled", weighting="symm", cheb_degree=3)
+    with ctx:
+        assert ctx.pair_sweeps() == (True, True) and ctx.pair_waves() == waves and ctx.pair_zchunks() == zchunks
+        plan, _ = pkg.pair_plan(ctx.params, 256)  # (ASM_PAIR_ZCHUNKS applies to the plan as well)
+        assert plan["nzc"] <= min(zchunks, nc[2]) and plan["nzc"] * plan["zlen"] >= nc[2] > (plan["nzc"] - 1) * plan["zlen"]
+        cheb = orc.Chebyshev(orc.LaplaceOperator(mesh), orc.ASPoissonPreconditioner(mesh, 1, "symm"), degree=3, lambda_max=1.8)
+        ctx.set_eigenvalue(1.8)
+        rng = np.random.default_rng(13)
+        b, x0 = rng.uniform(-1, 1, mesh.n_dofs), rng.uniform(-1, 1, mesh.n_dofs)
+        bv, xv = ctx.vector(b), ctx.vector(x0)
+        ctx.cheb_step(xv, bv)
+        assert rel(xv.get(), cheb.step(x0, b)) < TOL
+
+
+def test_measured_pick_is_consistent(pkg, monkeypatch):
+    """without ASM_PAIR a context measures chunk counts, forms and families when it is created: whatever it picks, the step
+    equals the tiled kernels' (and a second context of the same shape takes the same pick from the cache)"""
+    for v in ("ASM_PAIR", "ASM_PAIR_WAVES", "ASM_PAIR_ZCHUNKS"):
+        monkeypatch.delenv(v, raising=False)
+    rng = np.random.default_rng(17)
+    picks, out = [], []
+    for rep in range(3):
+        if rep == 2:
+            monkeypatch.setenv("ASM_PAIR", "0")
+        with pkg.Context(degree=4, n_cells=(24, 16, 12), boundary="dirichlet", cheb_degree=2, kernel="tiled") as ctx:
+            picks.append((ctx.pair_sweeps(), ctx.pair_zchunks(), ctx.pair_waves()))
+            if not out:
+                b, x0 = rng.uniform(-1, 1, ctx.n_dofs), rng.uniform(-1, 1, ctx.n_dofs)
+            ctx.set_eigenvalue(1.7)
+            bv, xv = ctx.vector(b), ctx.vector(x0)
+            ctx.cheb_step(xv, bv)
+            out.append(xv.get())
+    assert picks[0] == picks[1] and picks[2][0] == (False, False)
+    assert rel(out[0], out[2]) < TOL and rel(out[1], out[2]) < TOL
+
+
 @pytest.mark.parametrize("what", ["op", "precond"])
 @pytest.mark.parametrize("world,n_cells", [(2, (5, 4, 6)), (4, (4, 6, 6)), (8, (6, 6, 6))])
 @pytest.mark.parametrize("boundary", ["dirichlet", "periodic"])
