@@ -90,7 +90,7 @@ def test_pair_not_used_where_it_does_not_apply(pkg, force_pair):
         assert ctx.pair_sweeps() == (False, False)
 
 
-@pytest.mark.parametrize("nc,periodic,degree", [((80, 80, 80), False, 1), ((80, 80, 80), False, 3), ((64, 32, 32), True, 2)])
+@pytest.mark.parametrize("nc,periodic,degree", [((80, 80, 80), False, 1), ((80, 80, 80), False, 3), ((64, 32, 32), True, 2), ((128, 128, 96), False, 1)])
 def test_full_size_pair_equals_tiled(pkg, monkeypatch, nc, periodic, degree):
     """the bench workload at full size: the wave-pair kernels against the tiled kernels (which
     test_gpu_parity_configs.py::test_full_size_bench_workload pins on the threaded C++ restatement)"""
