@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <array>
 #include <condition_variable>
 #include <mutex>
@@ -218,6 +219,22 @@ namespace
     HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     *d = (const T *)p;
     return ASM_OK;
+  }
+
+  // gives a table of upload() back (tables of candidates a measurement did not pick); nothing may be using it any more
+  template <typename T>
+  void
+  release(asm_ctx *ctx, const T *&d)
+  {
+    if (d == nullptr)
+      return;
+    const auto it = std::find(ctx->allocs.begin(), ctx->allocs.end(), (void *)d);
+    if (it != ctx->allocs.end())
+      {
+        (void)hipFree(*it);
+        ctx->allocs.erase(it);
+      }
+    d = nullptr;
   }
 
   int
@@ -987,7 +1004,7 @@ namespace
   // scratch vectors.  All candidates sum the contributions to a DoF in the same order: the choice
   // does not change results.  ASM_TILED_ROWS=0|9|10|11 fixes it (experiments).
   std::mutex                         g_tune_mutex;
-  std::map<std::array<int, 14>, int> g_tune_cache;
+  std::map<std::array<int, 15>, int> g_tune_cache;
   int
   tune_tiled_laplace(asm_ctx *ctx)
   {
@@ -1002,7 +1019,7 @@ namespace
     // one measurement per device, block shape and boundary kinds in a process: contexts of the same shape (the ranks'
     // blocks in a loopback group, repeated creation) take the same variant, and a creation beside other work on the GPU
     // does not measure again (ASM_TILED_ROWS still overrides)
-    std::array<int, 14> key;
+    std::array<int, 15> key;
     key[0] = ctx->device;
     for (int d = 0; d < 3; ++d)
       {
@@ -1012,15 +1029,19 @@ namespace
         key[10 + d] = ctx->g.ext_hi[d] - ctx->g.ext_lo[d];
       }
     key[13] = ctx->op.cartesian;
-    {
-      std::lock_guard<std::mutex> lock(g_tune_mutex);
-      const auto                  hit = g_tune_cache.find(key);
-      if (hit != g_tune_cache.end())
-        {
-          ctx->laplace_rows = hit->second;
-          return ASM_OK;
-        }
-    }
+    key[14] = ctx->n_cu;
+    // (overrides of the tiling change what is measured: such contexts measure for themselves)
+    const bool use_cache = std::getenv("ASM_TILED_ZCHUNKS") == nullptr && std::getenv("ASM_TILED_TAIL") == nullptr;
+    if (use_cache)
+      {
+        std::lock_guard<std::mutex> lock(g_tune_mutex);
+        const auto                  hit = g_tune_cache.find(key);
+        if (hit != g_tune_cache.end())
+          {
+            ctx->laplace_rows = hit->second;
+            return ASM_OK;
+          }
+      }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -1071,13 +1092,17 @@ namespace
         }
     ctx->order_a = order_of[pick_i];
     ctx->order_p = order_of[0]; // (the FDM sweep is the first-generation kernel: same tiling as candidate 0)
+    for (int i = 1; i < 4; ++i)
+      if (i != pick_i)
+        release(ctx, order_of[i]); // (every launch above has completed: hipEventSynchronize)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ctx->laplace_rows = pick;
-    {
-      std::lock_guard<std::mutex> lock(g_tune_mutex);
-      g_tune_cache[key] = pick;
-    }
+    if (use_cache)
+      {
+        std::lock_guard<std::mutex> lock(g_tune_mutex);
+        g_tune_cache[key] = pick;
+      }
     HIP_TRY(hipMemsetAsync(ctx->T, 0, ctx->s.n_alloc * sizeof(double), ctx->stream));
     return ASM_OK;
   }
@@ -1085,7 +1110,7 @@ namespace
   // Wave-pair or tiled kernel, per sweep: measured once per device, block shape and boundary kinds in a process (the
   // faster one depends on how the tiles of either family fit the block); ASM_PAIR=1 / 0 takes the pair kernels wherever
   // they apply / nowhere.  Called when everything else of the context stands (tables, work orders, scratch vectors).
-  std::map<std::array<int, 14>, int> g_pair_cache; // bit 0: A, bit 1: P
+  std::map<std::array<int, 15>, int> g_pair_cache; // bit 0: A, bit 1: P, bit 2: two waves per tile, from bit 3: z chunks
   int
   tune_pair(asm_ctx *ctx)
   {
@@ -1112,9 +1137,10 @@ namespace
         return ASM_OK;
       std::vector<int> order;
       pair_order(ctx->g, ctx->n_cu, order, zchunks);
+      release(ctx, ctx->order_pair); // (the table of the chunk count before: its launches have completed)
       return upload(ctx, order, &ctx->order_pair);
     };
-    std::array<int, 14> key;
+    std::array<int, 15> key;
     key[0] = ctx->device;
     for (int d = 0; d < 3; ++d)
       {
@@ -1124,6 +1150,7 @@ namespace
         key[10 + d] = ctx->g.ext_hi[d] - ctx->g.ext_lo[d];
       }
     key[13] = (ctx->kron_a.valid ? 1 : 0) | (ctx->kron_p.valid ? 2 : 0) | (ctx->s.prm.weighting_type << 2);
+    key[14] = ctx->n_cu;
     {
       std::lock_guard<std::mutex> lock(g_tune_mutex);
       const auto                  hit = g_pair_cache.find(key);

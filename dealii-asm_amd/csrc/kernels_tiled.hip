@@ -921,10 +921,21 @@ namespace asmamd
             lo.y = rr[1];
             hi.x = rr[2];
             hi.y = rr[3];
-            // written once, not read again by this sweep: streaming stores (measured: -1.6 % per step on the Dirichlet box,
-            // -4 % on the periodic one)
-            __builtin_nontemporal_store(lo, (dbl2_u *)(a.dst + off));
-            __builtin_nontemporal_store(hi, (dbl2_u *)(a.dst + off + 2));
+            // written once, not read again by this sweep: streaming stores for the FDM sweeps (round 2: -1.6 % per step on the
+            // Dirichlet box, -4 % on the periodic one; round 4 re-measured: write-back stores cost them 1.3-2 %).  The Laplace
+            // sweeps store through the L2 since round 4: -4.4 % at 80^3, -2.8 % at 128x128x96, -1.6 % on the periodic box
+            // (their result is the residual the FDM sweep reads next, and a tile row of 11 cells = 352 B leaves half a 64-byte
+            // sector to the neighbouring tile, which streaming stores write separately)
+            if (MODE == OP_PLAIN || MODE == OP_RESIDUAL)
+              {
+                *(dbl2_u *)(a.dst + off)     = lo;
+                *(dbl2_u *)(a.dst + off + 2) = hi;
+              }
+            else
+              {
+                __builtin_nontemporal_store(lo, (dbl2_u *)(a.dst + off));
+                __builtin_nontemporal_store(hi, (dbl2_u *)(a.dst + off + 2));
+              }
           }
       };
       // Only the rows sub = 0 receive something in the y merge: every other row is final before the barrier and is
@@ -1043,6 +1054,10 @@ namespace asmamd
       // end here.  s_barrier waits for the surviving waves of a workgroup only, so the others go on as a smaller workgroup
       // (fewer waves at the LDS and in the vector-memory path per layer); the cooperative table loads below run over the
       // surviving threads.
+      // INVARIANT for every edit below this line (all three tiled kernels): a block-wide cooperative loop strides by
+      // nt_active, never by NT / blockDim.x, and no LDS hand-off may expect data from a wave at or above nt_active / 64 -
+      // those waves are gone.  The diagnostic builds (-DASM_STAMP, workgroup trace) follow the same rule;
+      // -DASM_EARLY_EXIT=0 keeps all waves alive (the A/B build of profiles/r03_tiled_kernel_experiments.txt).
 #ifndef ASM_EARLY_EXIT
 #  define ASM_EARLY_EXIT 1
 #endif
