@@ -80,6 +80,8 @@ struct asm_ctx
   // tiled kernels take the sweep); ASM_PAIR=0 switches them off
   DevKron                  kron_a{}, kron_p{};
   const int *              order_pair = nullptr; // work order of the wave-pair sweeps (pair_order)
+  const int *              order_pair_phase = nullptr; // ... of their two-phase launches (pair_phase_order)
+  int                      pair_n_first     = 0;
   bool                     pair_a = false, pair_p = false; // which sweeps take the wave-pair kernel (tune_pair)
   int                      pair_zchunks = 0;               // ... with how many z chunks (0: the schedule model's choice)
   int                      pair_waves = 0;                 // ... and waves per tile (2, or 0 / 4: four where the update has them)
@@ -235,6 +237,28 @@ namespace
         ctx->allocs.erase(it);
       }
     d = nullptr;
+  }
+
+  // the work-order tables of the wave-pair sweeps for a number of z chunks (0: the schedule model's): single-phase order
+  // and the order of the two-phase launches; the tables they replace must not be in use any more
+  int
+  upload_pair_orders(asm_ctx *ctx, const int zchunks)
+  {
+    release(ctx, ctx->order_pair);
+    release(ctx, ctx->order_pair_phase);
+    std::vector<int> order;
+    if (std::getenv("ASM_NO_TILED_ORDER") == nullptr)
+      {
+        pair_order(ctx->g, ctx->n_cu, order, zchunks);
+        if (const int err = upload(ctx, order, &ctx->order_pair))
+          return err;
+      }
+    bool iface[3][2];
+    for (int d = 0; d < 3; ++d)
+      for (int f = 0; f < 2; ++f)
+        iface[d][f] = ctx->s.face[d][f] == FACE_INTERFACE;
+    ctx->pair_n_first = pair_phase_order(ctx->g, ctx->n_cu, iface, order, zchunks);
+    return upload(ctx, order, &ctx->order_pair_phase);
   }
 
   int
@@ -624,6 +648,8 @@ namespace
     a.rows   = ctx->laplace_rows;
     a.order  = (a.mode == OP_PLAIN || a.mode == OP_RESIDUAL) ? ctx->order_a : ctx->order_p;
     a.pair_order = ctx->order_pair;
+    a.pair_phase_order = ctx->order_pair_phase;
+    a.pair_n_first     = ctx->pair_n_first;
     a.pair_zchunks = ctx->pair_zchunks;
     a.pair_waves   = ctx->pair_waves;
     if (!ov && ctx->debug_two_phase)
@@ -1133,12 +1159,7 @@ namespace
       if (zchunks == ctx->pair_zchunks)
         return ASM_OK;
       ctx->pair_zchunks = zchunks;
-      if (std::getenv("ASM_NO_TILED_ORDER") != nullptr)
-        return ASM_OK;
-      std::vector<int> order;
-      pair_order(ctx->g, ctx->n_cu, order, zchunks);
-      release(ctx, ctx->order_pair); // (the table of the chunk count before: its launches have completed)
-      return upload(ctx, order, &ctx->order_pair);
+      return upload_pair_orders(ctx, zchunks); // (the launches with the tables of the chunk count before have completed)
     };
     std::array<int, 15> key;
     key[0] = ctx->device;
@@ -1186,6 +1207,8 @@ namespace
           a->rows         = ctx->laplace_rows;
           a->order        = a == &ap ? ctx->order_p : ctx->order_a;
           a->pair_order   = ctx->order_pair;
+          a->pair_phase_order = ctx->order_pair_phase;
+          a->pair_n_first     = ctx->pair_n_first;
           a->pair_zchunks = ctx->pair_zchunks;
           a->pair_waves   = ctx->pair_waves;
         }
@@ -1947,13 +1970,9 @@ asm_create(const asm_params *p, asm_ctx **out)
   // single-phase tiled sweeps: the workgroups at Dirichlet faces first (kernels.h: tiled_order); ASM_NO_TILED_ORDER keeps
   // the launch positions (experiments)
   // (tune_tiled_laplace has set the tables of a context that measures its candidates; the others:)
-  if ((ctx->kron_a.valid || ctx->kron_p.valid) && std::getenv("ASM_NO_TILED_ORDER") == nullptr)
-    {
-      std::vector<int> order;
-      pair_order(ctx->g, ctx->n_cu, order);
-      if ((err = upload(ctx, order, &ctx->order_pair)))
-        return fail(err);
-    }
+  if (ctx->kron_a.valid || ctx->kron_p.valid)
+    if ((err = upload_pair_orders(ctx, 0)))
+      return fail(err);
   if ((ctx->s.laplace_tiled || ctx->s.fdm_tiled) && std::getenv("ASM_NO_TILED_ORDER") == nullptr && ctx->order_p == nullptr)
     {
       std::vector<int> order;

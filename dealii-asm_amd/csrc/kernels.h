@@ -80,6 +80,10 @@ namespace asmamd
     const int *order = nullptr;
     // the same for the wave-pair sweep (pair_order), and its number of z chunks (0: the schedule model's choice)
     const int *pair_order = nullptr;
+    // ... and of its two-phase launches: the first pair_n_first entries are phase 1 (pair_phase_order)
+    const int *pair_phase_order = nullptr;
+    int        pair_n_first     = 0;
+    int        pair_n_march = 0, pair_order_offset = 0; // set by the launcher (kernels_pair.hip: launch_pair)
     int        pair_zchunks = 0;
     int        pair_waves   = 0; // waves per tile of the wave-pair sweep: 2, or 0 / 4 = four where the mode has them
   };
@@ -108,6 +112,7 @@ namespace asmamd
   void pair_chunk_candidates(const DevGrid &g, int n_cu, std::vector<int> &zchunks);
   // the tiling of the pair sweep (host side): out = {tiles x, tiles y, z chunks, layers per chunk, first cell x, first cell y}
   void pair_plan(const DevGrid &g, int n_cu, int out[6], int zchunks = 0);
+  int  pair_phase_order(const DevGrid &g, int n_cu, const bool iface[3][2], std::vector<int> &order, int zchunks = 0);
 
   // ---- vector kernels (kernels_vector.hip)
   // elementwise over the whole allocation

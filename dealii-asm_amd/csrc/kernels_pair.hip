@@ -812,7 +812,12 @@ namespace asmamd
       constexpr int  NZC     = z_columns(NW);
       constexpr int  NT      = 64 * NW;
       // workgroups b and b + 8 land on the same XCD: contiguous ranges of the work per XCD (L2 locality of neighbouring tiles)
-      const int n_march = tl.ntx * tl.nty * tl.nzc;
+      // Two-phase launches (TiledArgs::phase 1 / 2; the ghost exchange of the result runs beside phase 2): a.pair_phase_order
+      // lists the workgroups at the block's rank interfaces first, padded with others to whole rounds (pair_phase_order);
+      // phase 1 = its first a.pair_n_first entries and the Dirichlet planes, phase 2 the rest.
+      // (the launcher has resolved the phase: a.pair_n_march workgroups march, their work indices are at a.pair_order +
+      //  a.pair_order_offset)
+      const int n_march = a.pair_n_march;
       if ((int)blockIdx.x >= n_march)
         {
           // (the last workgroups of the launch: the Dirichlet planes)
@@ -820,8 +825,8 @@ namespace asmamd
           return;
         }
       int wi = (int)xcd_block(blockIdx.x, n_march);
-      if (a.pair_order != nullptr) // expensive workgroups first (pair_order); a scalar load
-        wi = ((const __attribute__((address_space(4))) int *)a.pair_order)[wi];
+      if (a.pair_order != nullptr) // expensive workgroups first (pair_order) / phase order; a scalar load
+        wi = ((const __attribute__((address_space(4))) int *)a.pair_order)[wi + a.pair_order_offset];
       // (integer division runs on the vector unit even for wave-uniform values: back to scalar registers explicitly, or
       //  everything derived from the chunk index - the plane addresses the asm requests take as scalar operands - stays there)
       const int tx = __builtin_amdgcn_readfirstlane(wi % tl.ntx), ty = __builtin_amdgcn_readfirstlane((wi / tl.ntx) % tl.nty),
@@ -1407,8 +1412,18 @@ namespace asmamd
             }
           done.fetch_or(bit, std::memory_order_release);
         }
-      hipLaunchKernelGGL((pair_sweep_kernel<MODE, NW>), dim3(tl.ntx * tl.nty * tl.nzc + tl.n_face), dim3(64 * NW), L_TOTAL * sizeof(double), st, g, k, a,
-                         tl);
+      // the phase, resolved for the kernel: how many workgroups march and where their work indices are
+      TiledArgs b   = a;
+      const int n_all = tl.ntx * tl.nty * tl.nzc;
+      b.pair_n_march  = a.phase == 0 ? n_all : (a.phase == 1 ? a.pair_n_first : n_all - a.pair_n_first);
+      if (a.phase != 0)
+        {
+          b.pair_order        = a.pair_phase_order;
+          b.pair_order_offset = a.phase == 2 ? a.pair_n_first : 0;
+        }
+      const int grid = b.pair_n_march + (a.phase != 2 ? tl.n_face : 0); // (the Dirichlet planes: with phase 1)
+      if (grid > 0)
+        hipLaunchKernelGGL((pair_sweep_kernel<MODE, NW>), dim3(grid), dim3(64 * NW), L_TOTAL * sizeof(double), st, g, k, b, tl);
       return true;
     }
     // four waves per tile unless the mode or the caller (TiledArgs::pair_waves: the context's measurement or ASM_PAIR_WAVES
@@ -1453,6 +1468,30 @@ namespace asmamd
     return (int)order.size();
   }
 
+  // work indices of a two-phase launch: the workgroups with the first / last tile or chunk of a direction whose face is a
+  // rank interface (they produce what the neighbours ghost), then - from position n_first = their number rounded up to whole
+  // rounds of workgroup slots - the others; returns n_first
+  int
+  pair_phase_order(const DevGrid &g, const int n_cu, const bool iface[3][2], std::vector<int> &order, const int zchunks)
+  {
+    const PairTiling tl = make_pair_tiling(g, n_cu, zchunks);
+    const int        n  = tl.ntx * tl.nty * tl.nzc;
+    std::vector<int> inner;
+    order.clear();
+    for (int w = 0; w < n; ++w)
+      {
+        const int t[3] = {w % tl.ntx, (w / tl.ntx) % tl.nty, w / (tl.ntx * tl.nty)}, nt[3] = {tl.ntx, tl.nty, tl.nzc};
+        bool      bd   = false;
+        for (int d = 0; d < 3; ++d)
+          bd = bd || (iface[d][0] && t[d] == 0) || (iface[d][1] && t[d] == nt[d] - 1);
+        (bd ? order : inner).push_back(w);
+      }
+    const long long slots   = 2ll * (n_cu > 0 ? n_cu : 256);
+    const int       n_first = order.empty() ? 0 : (int)std::min<long long>(n, ((long long)order.size() + slots - 1) / slots * slots);
+    order.insert(order.end(), inner.begin(), inner.end());
+    return n_first;
+  }
+
   void
   pair_plan(const DevGrid &g, const int n_cu, int out[6], const int zchunks)
   {
@@ -1468,7 +1507,7 @@ namespace asmamd
   bool
   pair_sweep(const DevGrid &g, const DevKron &k, const TiledArgs &a, hipStream_t st)
   {
-    if (g.p != P || !k.valid || a.phase != 0)
+    if (g.p != P || !k.valid || (a.phase != 0 && a.pair_phase_order == nullptr))
       return false;
     // 32-bit byte offsets inside a DoF plane
     if (g.stride[2] * 8 >= (1ll << 31))

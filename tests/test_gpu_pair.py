@@ -159,3 +159,11 @@ def test_measured_pick_is_consistent(pkg, monkeypatch):
 def test_pair_partitioned(pkg, force_pair, what, world, n_cells, boundary):
     """blocks with ghost planes and halo cells of lower ranks: the partitioned result equals the single-rank one"""
     assert run_partitioned(pkg, world, n_cells, boundary, "tiled", what) < TOL
+
+
+@pytest.mark.parametrize("what", ["op", "precond"])
+@pytest.mark.parametrize("world,n_cells", [(2, (9, 4, 6)), (4, (4, 9, 6)), (8, (6, 6, 6))])
+@pytest.mark.parametrize("boundary", ["dirichlet", "periodic"])
+def test_pair_partitioned_two_phase(pkg, force_pair, what, world, n_cells, boundary):
+    """two-phase launches of the pair kernels (the workgroups at rank interfaces first, as with an overlapped exchange)"""
+    assert run_partitioned(pkg, world, n_cells, boundary, "tiled", what, two_phase=True) < TOL
