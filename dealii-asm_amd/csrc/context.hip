@@ -1211,15 +1211,32 @@ namespace
           a->pair_n_first     = ctx->pair_n_first;
           a->pair_zchunks = ctx->pair_zchunks;
           a->pair_waves   = ctx->pair_waves;
+          for (int d = 0; d < 3; ++d)
+            for (int f = 0; f < 2; ++f)
+              a->iface[d][f] = ctx->s.face[d][f] == FACE_INTERFACE;
         }
       const bool was_a = ctx->pair_a, was_p = ctx->pair_p;
       ctx->pair_a = ctx->pair_p = true;
-      const auto step           = [&]() {
+      // (a block with rank interfaces runs its sweeps inside the Chebyshev iteration in two phases, the ghost exchange
+      //  beside the second one: the families are compared in that form - the tiled kernels then chunk differently)
+      // (asm_comm_init switches the overlapped exchange on for a tiled context with neighbours unless ASM_NO_OVERLAP)
+      const bool two_phase = multi_rank(ctx) && std::getenv("ASM_NO_OVERLAP") == nullptr;
+      const auto sweep     = [&](TiledArgs &a, const bool fdm, const bool pair) {
+        bool ok = true;
+        for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 2 : 0) && ok; ++phase)
+          {
+            a.phase = phase;
+            ok      = fdm ? (pair ? pair_fdm(ctx, a, ctx->stream) : fdm_tiled(ctx->g, ctx->f, a, ctx->stream)) :
+                            (pair ? pair_laplace(ctx, a, ctx->stream) : laplace_tiled(ctx->g, ctx->op, a, ctx->stream));
+          }
+        return ok;
+      };
+      const auto step = [&]() {
         bool ok = true;
         if (have_a)
-          ok = pair_a ? pair_laplace(ctx, aa, ctx->stream) : laplace_tiled(ctx->g, ctx->op, aa, ctx->stream);
+          ok = sweep(aa, false, pair_a);
         if (ok && have_p)
-          ok = pair_p ? pair_fdm(ctx, ap, ctx->stream) : fdm_tiled(ctx->g, ctx->f, ap, ctx->stream);
+          ok = sweep(ap, true, pair_p);
         return ok;
       };
       bool ok = true;
