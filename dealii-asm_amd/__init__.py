@@ -210,6 +210,7 @@ EXPORTED_SYMBOLS = [
     "asm_tiled_plan",
     "asm_pair_plan",
     "asm_pair_sweeps_in_use",
+    "asm_pair_tiles",
     "asm_pair_zchunks",
     "asm_pair_waves",
     "asm_mg_coarse_failures",
@@ -275,6 +276,7 @@ def load_library():
     lib.asm_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     lib.asm_tiled_laplace_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_pair_sweeps_in_use.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.asm_pair_tiles.argtypes = [C.POINTER(AsmParams), C.c_int32, C.POINTER(C.c_int32 * 6), C.c_int32, C.POINTER(C.c_int32)]
     lib.asm_pair_zchunks.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_pair_waves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.asm_pair_plan.argtypes = [C.POINTER(AsmParams), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
@@ -339,6 +341,18 @@ def pair_plan(params, n_cu=256):
         raise ValueError(lib.asm_last_error(None).decode())
     keys = ("ntx", "nty", "nzc", "zlen", "x_first", "y_first")
     return dict(zip(keys, list(plan))), list(order[: n.value])
+
+
+def pair_tiles(params, n_cu=256):
+    """asm_pair_tiles: [(x0, y0, cells x, cells y, owns first column | owns first row << 1, last ownable column), ...]"""
+    lib = load_library()
+    n = C.c_int32()
+    cap = 1 << 16
+    tiles = ((C.c_int32 * 6) * cap)()
+    err = lib.asm_pair_tiles(C.byref(params), n_cu, tiles, cap, C.byref(n))
+    if err:
+        raise ValueError(lib.asm_last_error(None).decode())
+    return [tuple(tiles[i]) for i in range(n.value)]
 
 
 def make_params(

@@ -2806,6 +2806,34 @@ asm_pair_plan(const asm_params *p, int32_t n_cu, int32_t plan[6], int32_t *order
   return ASM_OK;
 }
 
+// the tiles of that tiling: tiles[i] = {first cell x, y, cells in x, in y, bit 0 / 1: owns its first column / row (else: halo),
+// last cell column it may own}; *n_tiles entries (at most max_tiles are written)
+int
+asm_pair_tiles(const asm_params *p, int32_t n_cu, int32_t (*tiles)[6], int32_t max_tiles, int32_t *n_tiles)
+{
+  if (p == nullptr || n_tiles == nullptr)
+    return ASM_ERR_INVALID_VALUE;
+  HostSetup s;
+  if (!setup_layout(*p, s))
+    {
+      g_create_error = s.error;
+      return ASM_ERR_INVALID_VALUE;
+    }
+  if (s.g.p != 4)
+    {
+      g_create_error = "asm_pair_tiles: the wave-pair sweeps exist for degree 4";
+      return ASM_ERR_NOT_SUPPORTED;
+    }
+  std::vector<std::array<int, 6>> t;
+  pair_tiles(s.g, n_cu, t);
+  *n_tiles = (int32_t)t.size();
+  if (tiles != nullptr)
+    for (int i = 0; i < std::min<int>(max_tiles, (int)t.size()); ++i)
+      for (int k = 0; k < 6; ++k)
+        tiles[i][k] = t[i][k];
+  return ASM_OK;
+}
+
 // which tiled Laplace sweep the context uses: cell rows (waves) per workgroup, 8 = first generation, 9-11 = second
 // (measured at creation or fixed by ASM_TILED_ROWS); 0 = the context has no tiled Laplace sweep
 int

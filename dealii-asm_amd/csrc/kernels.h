@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <vector>
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
@@ -112,6 +113,7 @@ namespace asmamd
   void pair_chunk_candidates(const DevGrid &g, int n_cu, std::vector<int> &zchunks);
   // the tiling of the pair sweep (host side): out = {tiles x, tiles y, z chunks, layers per chunk, first cell x, first cell y}
   void pair_plan(const DevGrid &g, int n_cu, int out[6], int zchunks = 0);
+  void pair_tiles(const DevGrid &g, int n_cu, std::vector<std::array<int, 6>> &tiles, int zchunks = 0);
   int  pair_phase_order(const DevGrid &g, int n_cu, const bool iface[3][2], std::vector<int> &order, int zchunks = 0);
 
   // ---- vector kernels (kernels_vector.hip)

@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstdlib>
 #include <functional>
@@ -83,10 +84,19 @@ namespace asmamd
     typedef __attribute__((address_space(1))) double       *glb_ptr;
     typedef __attribute__((address_space(1))) dbl2_u       *glb_dbl2_ptr;
 
+    // Tiles: ntx x nty "main" tiles of 8 x 8 cells (7 x 7 owned), then - where the last tile column (row) of such a tiling
+    // would own three cell columns (rows) or less - n_rs strip tiles of 4 x 16 cells (3 x 15 owned) stacked along the block's
+    // right edge and n_ts strip tiles of 16 x 4 cells along its upper edge instead of it: 81 = 8 + 10 x 7 + 3 cell columns
+    // (80 cells and the one behind them) take 11 tile columns and 6 strips, not 12 columns whose last one is 3/7 full
+    // (133 instead of 144 tiles at 80^3, 342 instead of 361 at 128 x 128).  The shape is a run-time matter of the lane -> cell
+    // map only; tile index t = main tiles (x fastest), right strips (bottom up), upper strips (left to right).
     struct PairTiling
     {
       int ntx, nty, nzc, zlen;
       int x_first, y_first; // first cell of tile 0: -1 where the block has a cell below its first one, else 0
+      int n_rs, n_ts;       // strip tiles at the right / upper edge
+      int xs0, ys0;         // ... whose halo column / row is this cell (= the last cell the main tiles own)
+      __host__ __device__ int n_tiles() const { return ntx * nty + n_rs + n_ts; }
       // The Dirichlet planes, which the march neither reads nor writes, are set by n_face further workgroups at the end of
       // the launch (identity rows: the fused update of the source value).  They start as compute units fall free in the
       // launch's tail and cost next to nothing there; as a kernel of their own behind every sweep (vec_constrained*,
@@ -94,6 +104,51 @@ namespace asmamd
       int       n_face;
       long long face_dofs; // DoFs of all Dirichlet planes (stored extent of the two tangential directions)
     };
+
+    struct TileGeom
+    {
+      int  X0, Y0;     // cell of lane 0
+      int  lg_tx;      // log2 of the tile's width in cells: 3 (8 x 8), 2 (4 x 16), 4 (16 x 4)
+      bool lo_x, lo_y; // the tile starts at the block's first cell at a physical boundary: it owns its first column / row
+      int  x_max;      // cells beyond this column belong to another tile (upper strips next to the right strips)
+    };
+    __host__ __device__ __forceinline__ TileGeom
+    tile_geom(const PairTiling &tl, const int t)
+    {
+      TileGeom  q;
+      const int n_main = tl.ntx * tl.nty;
+      q.x_max          = 1 << 30;
+      if (t < n_main)
+        {
+          const int tx = t % tl.ntx, ty = t / tl.ntx;
+          q.X0    = tx * OX + tl.x_first;
+          q.Y0    = ty * OY + tl.y_first;
+          q.lg_tx = 3;
+          q.lo_x  = tx == 0 && tl.x_first == 0;
+          q.lo_y  = ty == 0 && tl.y_first == 0;
+        }
+      else if (t < n_main + tl.n_rs)
+        {
+          const int s = t - n_main;
+          q.X0    = tl.xs0;
+          q.Y0    = s * 15 + tl.y_first;
+          q.lg_tx = 2;
+          q.lo_x  = false;
+          q.lo_y  = s == 0 && tl.y_first == 0;
+        }
+      else
+        {
+          const int s = t - n_main - tl.n_rs;
+          q.X0    = s * 15 + tl.x_first;
+          q.Y0    = tl.ys0;
+          q.lg_tx = 4;
+          q.lo_x  = s == 0 && tl.x_first == 0;
+          q.lo_y  = false;
+          if (tl.n_rs > 0)
+            q.x_max = tl.xs0;
+        }
+      return q;
+    }
 
     __device__ __forceinline__ bool
     cell_computable(const DevGrid &g, const int d, const int c)
@@ -302,6 +357,7 @@ namespace asmamd
       // operands / dst: byte offset of row 0 of the DoFs the lane owns and the step to the next row (0: only row 0 exists)
       unsigned orow0, ostep;
       unsigned sstep; // the row stride in bytes (wave-uniform, kept with the rest)
+      int      tw;    // cells per tile row (8, 4 or 16): the lane below is tw lanes down
       __device__ __forceinline__ bool is(const unsigned f) const { return (flags & f) != 0u; }
       // (the tests are made again in every layer instead of being kept as lane masks over the march)
       __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(flags)); }
@@ -694,7 +750,7 @@ namespace asmamd
       double rb[P];
 #pragma unroll
       for (int i = 0; i < P; ++i)
-        rb[i] = __shfl_up(o[4 * 5 + i], TX, 64);
+        rb[i] = __shfl_up(o[4 * 5 + i], c.tw, 64);
       if (c.is(F_BELOW))
         {
 #pragma unroll
@@ -829,9 +885,10 @@ namespace asmamd
         wi = ((const __attribute__((address_space(4))) int *)a.pair_order)[wi + a.pair_order_offset];
       // (integer division runs on the vector unit even for wave-uniform values: back to scalar registers explicitly, or
       //  everything derived from the chunk index - the plane addresses the asm requests take as scalar operands - stays there)
-      const int tx = __builtin_amdgcn_readfirstlane(wi % tl.ntx), ty = __builtin_amdgcn_readfirstlane((wi / tl.ntx) % tl.nty),
-                zc = __builtin_amdgcn_readfirstlane(wi / (tl.ntx * tl.nty));
-      const int X0 = tx * OX + tl.x_first, Y0 = ty * OY + tl.y_first;
+      const int      n_tiles = tl.n_tiles();
+      const int      ti = __builtin_amdgcn_readfirstlane(wi % n_tiles), zc = __builtin_amdgcn_readfirstlane(wi / n_tiles);
+      const TileGeom tg = tile_geom(tl, ti);
+      const int      X0 = __builtin_amdgcn_readfirstlane(tg.X0), Y0 = __builtin_amdgcn_readfirstlane(tg.Y0);
 #ifndef ASM_PAIR_ABL
 #  define ASM_PAIR_ABL 0 // diagnostic builds (wrong results): 1 no plane requests, 2 no diagonal reads, 4 no scratchpad traffic, 8 no arithmetic in the z columns
 #endif
@@ -839,12 +896,12 @@ namespace asmamd
 #  ifndef ASM_PAIR_STAMP_TILE
 #    define ASM_PAIR_STAMP_TILE 0 // 0: a tile in the middle of the block, 1: at the low x face, 2: at the low x and y faces
 #  endif
-      const bool stamp_on = tx == (ASM_PAIR_STAMP_TILE >= 1 ? 0 : tl.ntx / 2) && ty == (ASM_PAIR_STAMP_TILE >= 2 ? 0 : tl.nty / 2) && zc == tl.nzc / 2 &&
+      const bool stamp_on = ti == (ASM_PAIR_STAMP_TILE >= 1 ? 0 : tl.ntx / 2) + tl.ntx * (ASM_PAIR_STAMP_TILE >= 2 ? 0 : tl.nty / 2) && zc == tl.nzc / 2 &&
                             threadIdx.x < 64;
       unsigned long long stamp_t = __builtin_amdgcn_s_memtime(), stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-      const int lane = threadIdx.x & 63, cl = lane % TX, rw = lane / TX;
+      const int lane = threadIdx.x & 63, cl = lane & ((1 << tg.lg_tx) - 1), rw = lane >> tg.lg_tx;
       const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 .. NW - 1, wave-uniform
       const int cx = X0 + cl, cy = Y0 + rw;
       Lane      c;
@@ -856,8 +913,9 @@ namespace asmamd
         ph_y              = cy == g.nc[1] && has_phantom(g, 1);
         cell_xy           = comp_x && comp_y;
         // a cell's DoFs (0..3)^2 belong to the tile that holds it outside its halo column / row; cells -1 are never owned
-        const bool own_x = cx >= 0 && (comp_x || ph_x) && (cl >= 1 || (tx == 0 && tl.x_first == 0));
-        const bool own_y = cy >= 0 && (comp_y || ph_y) && (rw >= 1 || (ty == 0 && tl.y_first == 0));
+        const bool own_x = cx >= 0 && (comp_x || ph_x) && (cl >= 1 || tg.lo_x) && cx <= tg.x_max;
+        const bool own_y = cy >= 0 && (comp_y || ph_y) && (rw >= 1 || tg.lo_y);
+        c.tw             = 1 << tg.lg_tx;
         owner            = own_x && own_y;
         c.flags          = (cell_xy ? F_CELL : 0u) | (owner ? F_OWNER : 0u) | (ph_x ? F_PH_X : 0u) | (ph_y ? F_PH_Y : 0u) |
                   ((owner && g.dirichlet(0, P * cx)) ? F_XD0 : 0u) | ((owner && g.dirichlet(1, P * cy)) ? F_YD0 : 0u) | (cl >= 1 ? F_LEFT : 0u) |
@@ -1243,15 +1301,17 @@ namespace asmamd
     // relative cost of a workgroup's layer: tiles with cells at a physical boundary take the sweeps of that direction with
     // full matrices (stage timers: profiles/r04_pair_stamps.txt)
     double
-    tile_cost(const DevGrid &g, const PairTiling &tl, const int tx, const int ty)
+    tile_cost(const DevGrid &g, const PairTiling &tl, const int t)
     {
-      const auto at_boundary = [&](const int d, const int c0) {
-        // cells c0 .. c0 + 7 of direction d; the first / last cell of a block at a physical boundary
+      const TileGeom q  = tile_geom(tl, t);
+      const int      tw = 1 << q.lg_tx, th = 64 >> q.lg_tx;
+      const auto at_boundary = [&](const int d, const int c0, const int width) {
+        // cells c0 .. c0 + width - 1 of direction d; the first / last cell of a block at a physical boundary
         const bool lo = !g.wrap[d] && g.ext_lo[d] == 0, hi = !g.wrap[d] && g.own_hi[d] == g.nc[d] * P;
-        return (lo && c0 <= 0) || (hi && c0 <= g.nc[d] - 1 && c0 + TX > g.nc[d] - 1);
+        return (lo && c0 <= 0) || (hi && c0 <= g.nc[d] - 1 && c0 + width > g.nc[d] - 1);
       };
       // (stage timers: +17 % per layer in a tile at a face, about twice that at an edge)
-      return 1.0 + (at_boundary(0, tx * OX + tl.x_first) ? 0.17 : 0.) + (at_boundary(1, ty * OY + tl.y_first) ? 0.17 : 0.);
+      return 1.0 + (at_boundary(0, q.X0, tw) ? 0.17 : 0.) + (at_boundary(1, q.Y0, th) ? 0.17 : 0.);
     }
     int
     chunk_layers(const DevGrid &g, const PairTiling &tl, const int zc)
@@ -1266,10 +1326,10 @@ namespace asmamd
     double
     schedule(const DevGrid &g, const PairTiling &tl, const long long slots, std::vector<int> *order)
     {
-      const int           n = tl.ntx * tl.nty * tl.nzc;
+      const int           nt = tl.n_tiles(), n = nt * tl.nzc;
       std::vector<double> cost(n);
       for (int w = 0; w < n; ++w)
-        cost[w] = tile_cost(g, tl, w % tl.ntx, (w / tl.ntx) % tl.nty) * (chunk_layers(g, tl, w / (tl.ntx * tl.nty)) + 0.5);
+        cost[w] = tile_cost(g, tl, w % nt) * (chunk_layers(g, tl, w / nt) + 0.5);
       std::vector<int> pos(n);
       for (int xcd = 0; xcd < 8; ++xcd)
         {
@@ -1344,6 +1404,48 @@ namespace asmamd
       tl.y_first = first(1);
       tl.ntx     = tiles(0, tl.x_first, OX);
       tl.nty     = tiles(1, tl.y_first, OY);
+      tl.n_rs = tl.n_ts = 0;
+      tl.xs0 = tl.ys0 = 0;
+      {
+        // strips instead of a last tile column / row that would own 1..3 cell columns / rows: whichever of the four
+        // combinations has the fewest tiles (ASM_PAIR_NO_STRIPS: experiments)
+        const int  last[2] = {g.nc[0] - 1 + (has_phantom(g, 0) ? 1 : 0), g.nc[1] - 1 + (has_phantom(g, 1) ? 1 : 0)};
+        const int  full[2] = {tl.ntx, tl.nty}, frst[2] = {tl.x_first, tl.y_first}, own[2] = {OX, OY};
+        bool       can[2];
+        for (int d = 0; d < 2; ++d)
+          {
+            const int left = last[d] - (frst[d] + (full[d] - 1) * own[d]); // cells the last tile column / row would own
+            can[d]         = full[d] >= 2 && left >= 1 && left <= 3 && std::getenv("ASM_PAIR_NO_STRIPS") == nullptr;
+          }
+        const auto strips = [&](const int first_cell, const int upto) { // tiles of 15 owned cells that own everything up to `upto`
+          int n = 1;
+          while (first_cell + n * 15 < upto)
+            ++n;
+          return n;
+        };
+        long long best_n = (long long)tl.ntx * tl.nty;
+        for (int sx = 0; sx <= (can[0] ? 1 : 0); ++sx)
+          for (int sy = 0; sy <= (can[1] ? 1 : 0); ++sy)
+            {
+              if (sx + sy == 0)
+                continue;
+              const int ntx = full[0] - sx, nty = full[1] - sy;
+              const int xs0 = tl.x_first + ntx * OX, ys0 = tl.y_first + nty * OY;
+              const int n_rs = sx ? strips(tl.y_first, last[1]) : 0;              // right strips: all rows
+              const int n_ts = sy ? strips(tl.x_first, sx ? xs0 : last[0]) : 0; // upper strips: the main tiles' columns
+              const long long n = (long long)ntx * nty + n_rs + n_ts;
+              if (n < best_n)
+                {
+                  best_n  = n;
+                  tl.ntx  = ntx;
+                  tl.nty  = nty;
+                  tl.n_rs = n_rs;
+                  tl.n_ts = n_ts;
+                  tl.xs0  = xs0;
+                  tl.ys0  = ys0;
+                }
+            }
+      }
       // z chunks: two workgroups per compute unit run at a time; a chunk costs its layers plus the halo layer below it,
       // tiles at physical boundaries cost more per layer: the chunk count whose simulated schedule ends first
       const long long slots = 2ll * n_cu;
@@ -1359,7 +1461,7 @@ namespace asmamd
             {
               tl.zlen = (g.nc[2] + nzc - 1) / nzc;
               tl.nzc  = (g.nc[2] + tl.zlen - 1) / tl.zlen;
-              if (tl.nzc == last_chunks || (long long)tl.ntx * tl.nty * tl.nzc > 16384)
+              if (tl.nzc == last_chunks || (long long)tl.n_tiles() * tl.nzc > 16384)
                 continue;
               last_chunks      = tl.nzc;
               const double end = schedule(g, tl, slots, nullptr);
@@ -1414,7 +1516,7 @@ namespace asmamd
         }
       // the phase, resolved for the kernel: how many workgroups march and where their work indices are
       TiledArgs b   = a;
-      const int n_all = tl.ntx * tl.nty * tl.nzc;
+      const int n_all = tl.n_tiles() * tl.nzc;
       b.pair_n_march  = a.phase == 0 ? n_all : (a.phase == 1 ? a.pair_n_first : n_all - a.pair_n_first);
       if (a.phase != 0)
         {
@@ -1475,15 +1577,16 @@ namespace asmamd
   pair_phase_order(const DevGrid &g, const int n_cu, const bool iface[3][2], std::vector<int> &order, const int zchunks)
   {
     const PairTiling tl = make_pair_tiling(g, n_cu, zchunks);
-    const int        n  = tl.ntx * tl.nty * tl.nzc;
+    const int        nt = tl.n_tiles(), n = nt * tl.nzc;
     std::vector<int> inner;
     order.clear();
     for (int w = 0; w < n; ++w)
       {
-        const int t[3] = {w % tl.ntx, (w / tl.ntx) % tl.nty, w / (tl.ntx * tl.nty)}, nt[3] = {tl.ntx, tl.nty, tl.nzc};
-        bool      bd   = false;
-        for (int d = 0; d < 3; ++d)
-          bd = bd || (iface[d][0] && t[d] == 0) || (iface[d][1] && t[d] == nt[d] - 1);
+        const TileGeom q   = tile_geom(tl, w % nt);
+        const int      zc  = w / nt, c0[2] = {q.X0, q.Y0}, wd[2] = {1 << q.lg_tx, 64 >> q.lg_tx};
+        bool           bd  = (iface[2][0] && zc == 0) || (iface[2][1] && zc == tl.nzc - 1);
+        for (int d = 0; d < 2; ++d) // the tile holds the block's first / last cell of the direction
+          bd = bd || (iface[d][0] && c0[d] <= 0) || (iface[d][1] && c0[d] + wd[d] > g.nc[d] - 1);
         (bd ? order : inner).push_back(w);
       }
     const long long slots   = 2ll * (n_cu > 0 ? n_cu : 256);
@@ -1502,6 +1605,19 @@ namespace asmamd
     out[3]              = tl.zlen;
     out[4]              = tl.x_first;
     out[5]              = tl.y_first;
+  }
+
+  // every tile of the tiling: {first cell x, y, cells in x, in y, owns its first column (1) / row (2), last column it may own}
+  void
+  pair_tiles(const DevGrid &g, const int n_cu, std::vector<std::array<int, 6>> &tiles, const int zchunks)
+  {
+    const PairTiling tl = make_pair_tiling(g, n_cu, zchunks);
+    tiles.clear();
+    for (int t = 0; t < tl.n_tiles(); ++t)
+      {
+        const TileGeom q = tile_geom(tl, t);
+        tiles.push_back({q.X0, q.Y0, 1 << q.lg_tx, 64 >> q.lg_tx, (q.lo_x ? 1 : 0) | (q.lo_y ? 2 : 0), q.x_max});
+      }
   }
 
   bool

@@ -351,9 +351,14 @@ int asm_measure_copy_bandwidth(asm_ctx *ctx, int64_t bytes, int32_t reps, double
  * order).  Diagnostic: lets the tiling be checked without a device (tests/test_abi_cpu.py). */
 int asm_tiled_plan(const asm_params *p, int32_t n_cu, int32_t rows, int32_t plan[8], int32_t *order, int32_t max_order, int32_t *n_order);
 /* The same for the wave-pair sweeps (degree 4 on Cartesian cells; csrc/kernels_pair.hip): plan = {tiles x, tiles y, z chunks,
- * layers per chunk, first cell of tile 0 in x, in y}; a tile = 8 x 8 cells of which 7 x 7 (all 8 where tile 0 starts at
- * cell 0) own their DoFs, the cell behind the block's last one owns the block's last DoF plane. */
+ * layers per chunk, first cell of tile 0 in x, in y} of the main tiles; a tile = 8 x 8 cells of which 7 x 7 (all 8 where tile 0
+ * starts at cell 0) own their DoFs, the cell behind the block's last one owns the block's last DoF plane. */
 int asm_pair_plan(const asm_params *p, int32_t n_cu, int32_t plan[6], int32_t *order, int32_t max_order, int32_t *n_order);
+/* ... and its tiles (plan[0] x plan[1] main tiles first, then the strip tiles that replace a last tile column / row of three
+ * cells or less): tiles[i] = {first cell x, y, cells in x, in y (8 x 8, 4 x 16 or 16 x 4), bit 0 / 1: the tile owns its first
+ * column / row (else they are its halo), last cell column it may own}; the work index of asm_pair_plan's order is
+ * tile + n_tiles * z chunk. */
+int asm_pair_tiles(const asm_params *p, int32_t n_cu, int32_t (*tiles)[6], int32_t max_tiles, int32_t *n_tiles);
 /* which sweeps of a tiled context run on the wave-pair kernels (measured against the tiled kernels when the context is
  * created; ASM_PAIR=1 / 0 fixes it): *laplace, *fdm = 1 / 0.  Replaces the same reference methods as the tiled kernels:
  * LaplaceOperatorMatrixFree::vmult (include/operator.h:1367-1430), ASPoissonPreconditioner::vmult (include/matrix_free.h:1023-1062). */

@@ -217,23 +217,39 @@ def test_chunk_count_model_of_the_tiled_sweeps(pkg):
 @pytest.mark.parametrize("nc,boundary", [((80, 80, 80), "dirichlet"), ((128, 128, 96), "dirichlet"), ((7, 8, 3), "dirichlet"), ((15, 9, 4), "neumann"),
                                          ((16, 16, 9), "periodic"), ((1, 1, 1), "dirichlet"), ((23, 57, 5), "dirichlet")])
 def test_pair_plan_covers_the_block(pkg, nc, boundary):
-    """asm_pair_plan (host only): the tiles of the wave-pair sweeps (8 x 8 cells, 7 x 7 of them owned, all 8 where tile 0
-    starts at cell 0) own every cell of the block once, plus the cell behind the last one where the block owns its last DoF
-    plane; the z chunks cover the layers; the work order is a permutation that keeps every XCD's contiguous range"""
+    """asm_pair_plan / asm_pair_tiles (host only): the tiles of the wave-pair sweeps - 8 x 8 cells of which 7 x 7 are owned (all 8
+    where a tile starts at cell 0 of a physical boundary), strip tiles of 4 x 16 / 16 x 4 cells where the last tile column / row
+    would own three cells or less - own every cell of the block exactly once, plus the cell behind the last one where the
+    block owns its last DoF plane; the z chunks cover the layers; the work order is a permutation that keeps every XCD's
+    contiguous range"""
     prm = pkg.make_params(degree=4, n_cells=nc, boundary=boundary)
     plan, order = pkg.pair_plan(prm, n_cu=256)
+    tiles = pkg.pair_tiles(prm, n_cu=256)
     periodic = boundary == "periodic"
-    for d, (nt, first) in enumerate(((plan["ntx"], plan["x_first"]), (plan["nty"], plan["y_first"]))):
-        assert first == (-1 if periodic else 0)
-        last = nc[d] - 1 if periodic else nc[d]  # non-periodic: the cell nc owns the plane 4 nc
-        owned = []
-        for t in range(nt):
-            c0 = t * 7 + first
-            owned += [c for c in range(c0, c0 + 8) if 0 <= c <= last and (c > c0 or (t == 0 and first == 0))]
-        assert sorted(owned) == list(range(last + 1)), (d, owned)
+    assert plan["x_first"] == plan["y_first"] == (-1 if periodic else 0)
+    last = [nc[d] - 1 if periodic else nc[d] for d in range(2)]  # non-periodic: the cell nc owns the plane 4 nc
+    owned = np.zeros((last[1] + 1, last[0] + 1), dtype=int)
+    for x0, y0, w, h, lo, x_max in tiles:
+        assert (w, h) in ((8, 8), (4, 16), (16, 4))
+        xs = [c for c in range(x0, x0 + w) if 0 <= c <= min(last[0], x_max) and (c > x0 or lo & 1)]
+        ys = [c for c in range(y0, y0 + h) if 0 <= c <= last[1] and (c > y0 or lo & 2)]
+        assert xs and ys, "a tile that owns nothing"
+        owned[np.ix_(ys, xs)] += 1
+    assert (owned == 1).all(), owned
+    assert len(tiles) <= plan["ntx"] * plan["nty"] + ((last[1] + 15) // 15 + 1) + ((last[0] + 15) // 15 + 1)
+    full = [-(-(last[d] + (1 if plan["x_first"] else 0) - (0 if periodic else 1)) // 7) for d in range(2)]
+    assert len(tiles) <= (full[0] + 1) * (full[1] + 1)
     assert plan["nzc"] * plan["zlen"] >= nc[2] and (plan["nzc"] - 1) * plan["zlen"] < nc[2]
-    n = plan["ntx"] * plan["nty"] * plan["nzc"]
+    n = len(tiles) * plan["nzc"]
     assert len(order) == n and sorted(order) == list(range(n))
     for xcd in range(8):
         begin, count = xcd * (n // 8) + min(xcd, n % 8), n // 8 + (1 if xcd < n % 8 else 0)
         assert sorted(order[begin:begin + count]) == list(range(begin, begin + count))
+
+
+def test_pair_strip_tiles_at_the_bench_sizes(pkg):
+    """80^3 and 128 x 128 x 96 cells: 81 = 8 + 10 x 7 + 3 and 129 = 8 + 17 x 7 + 2 cell columns - strips replace the last tile
+    column and row (133 instead of 144 tiles, 342 instead of 361)"""
+    for nc, n_plain, n_strips in (((80, 80, 80), 144, 11 * 11 + 6 + 6), ((128, 128, 96), 361, 18 * 18 + 9 + 9)):
+        tiles = pkg.pair_tiles(pkg.make_params(degree=4, n_cells=nc, boundary="dirichlet"))
+        assert len(tiles) == n_strips < n_plain, len(tiles)
