@@ -1274,21 +1274,26 @@ namespace
                   ctx->pair_waves = waves;
                   timed.emplace_back(time_step(!for_p, for_p), std::make_pair(cand[i], waves));
                 }
-        // (the three fastest once more: a box's clock drifts within the measurement)
+        // (the four fastest again, three interleaved rounds, the best of those for each: a box's clock drifts within the
+        //  measurement, and a first pass's lucky outlier must not decide)
         std::sort(timed.begin(), timed.end());
+        const std::size_t  n_final = std::min<std::size_t>(timed.size(), 4);
+        std::vector<float> again(n_final, 1e30f);
+        for (int round = 0; round < 3 && !err; ++round)
+          for (std::size_t i = 0; i < n_final && !err; ++i)
+            if (!(err = set_chunks(timed[i].second.first)))
+              {
+                ctx->pair_waves = timed[i].second.second;
+                again[i]        = std::min(again[i], time_step(!for_p, for_p));
+              }
         int   best = 0, best_waves = 0;
         float best_time = 1e30f;
-        for (std::size_t i = 0; i < timed.size() && i < 3 && !err; ++i)
-          if (!(err = set_chunks(timed[i].second.first)))
+        for (std::size_t i = 0; i < n_final; ++i)
+          if (again[i] < best_time)
             {
-              ctx->pair_waves = timed[i].second.second;
-              const float t   = std::min(timed[i].first, time_step(!for_p, for_p));
-              if (t < best_time)
-                {
-                  best_time  = t;
-                  best       = timed[i].second.first;
-                  best_waves = timed[i].second.second;
-                }
+              best_time  = again[i];
+              best       = timed[i].second.first;
+              best_waves = timed[i].second.second;
             }
         ctx->pair_waves = best_waves;
         if (!err)
