@@ -25,11 +25,16 @@
 //   * Nothing is parked in registers, so the accumulation registers are free: they take the NEXT layer's source planes
 //     and update operands, requested a whole layer ahead by plain global loads into FIXED registers the compiler never
 //     sees (one wave per SIMD has no other wave to hide a miss behind).  Audit of every build: no v_accvgpr_* outside
-//     the asm statements above a27, no scratch (tools/audit_pair.sh).
+//     the asm statements above a91 / a27 (three-term update) / a17 (four waves), no scratch, no flat instruction
+//     (tools/audit_pair.sh).
 //   * Merges: x by a DPP row shift, y by ds_bpermute, z in the transformed space (carry of 13 values per lane).
 //   * The cells c = nc of a direction whose last DoF plane belongs to the block do not exist but OWN that plane (their
 //     column / row 0): they run along with a zero diagonal and store what they receive from their neighbours.
-//   * Constrained DoFs are neither read (the tables zero their rows) nor written; the caller sets them.
+//   * Constrained DoFs are neither read (the tables zero their rows) nor written by the march; further workgroups of the same
+//     launch set them (constrained_dofs).
+//   * Tiles: 8 x 8 cells, and strips of 4 x 16 / 16 x 4 cells where a last tile column / row would own three cells or less
+//     (PairTiling, tile_geom).  z chunks and the form (two / four waves) are measured by the context (context.hip: tune_pair).
+//   * Two-phase launches for the overlapped ghost exchange of a partitioned run: pair_phase_order.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
