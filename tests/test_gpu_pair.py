@@ -167,3 +167,27 @@ def test_pair_partitioned(pkg, force_pair, what, world, n_cells, boundary):
 def test_pair_partitioned_two_phase(pkg, force_pair, what, world, n_cells, boundary):
     """two-phase launches of the pair kernels (the workgroups at rank interfaces first, as with an overlapped exchange)"""
     assert run_partitioned(pkg, world, n_cells, boundary, "tiled", what, two_phase=True) < TOL
+
+
+def test_pair_equals_tiled_on_random_blocks(pkg, monkeypatch):
+    """twenty blocks of random extents (all leftovers of the 7-cell tiling: plain last tiles and strip tiles) and boundary
+    kinds: a Chebyshev step of degree 2 with the pair kernels (both forms) against the tiled kernels"""
+    rng = np.random.default_rng(2024)
+    kinds = ["dirichlet", "neumann", "periodic"]
+    for case in range(20):
+        nc = tuple(int(v) for v in rng.integers(1, 40, 2)) + (int(rng.integers(1, 9)),)
+        bc = [kinds[int(k)] for k in rng.integers(0, 3, 3)]
+        b = x0 = None
+        out = {}
+        for pair, waves in (("0", "4"), ("1", "4"), ("1", "2")):
+            monkeypatch.setenv("ASM_PAIR", pair)
+            monkeypatch.setenv("ASM_PAIR_WAVES", waves)
+            with pkg.Context(degree=4, n_cells=nc, boundary=bc, cheb_degree=2, kernel="tiled", weighting="symm") as ctx:
+                if b is None:
+                    b, x0 = rng.uniform(-1, 1, ctx.n_dofs), rng.uniform(-1, 1, ctx.n_dofs)
+                ctx.set_eigenvalue(1.6)
+                bv, xv = ctx.vector(b), ctx.vector(x0)
+                ctx.cheb_step(xv, bv)
+                out[(pair, waves)] = xv.get()
+        for key in (("1", "4"), ("1", "2")):
+            assert rel(out[key], out[("0", "4")]) < TOL, (case, nc, bc, key)
